@@ -1,0 +1,113 @@
+/*
+ * pti_vae.h — C-ABI of libpti_vae_hip.so: hand-written HIP (gfx950 / CDNA4) kernels for the
+ * VAE training hot path of Sukikui/PTI-LDM-VAE.
+ *
+ * The reference has no FFI: its only seam is the Python class pti_ldm_vae.models.VAEModel
+ * (reference src/pti_ldm_vae/models/autoencoder.py:6-171), whose arithmetic is MONAI's
+ * AutoencoderKL reached through torch.nn ops (autoencoder.py:3,67-79,114).  Each entry point
+ * below replaces one of those implicit ATen/cuDNN kernels; the comment on each names the
+ * reference call it stands in for.  Host side: pti_ldm_vae_amd/_lib.py binds them with ctypes.
+ *
+ * Conventions (all entry points):
+ *   - plain device pointers + sizes, no torch types; launches ONLY on the given stream;
+ *   - never allocates, never synchronises, never throws;
+ *   - returns 0 on success or a negative PTI_E* code; pti_last_error_string() explains it;
+ *   - activations are NHWC bf16 (channels innermost) unless a parameter says otherwise;
+ *   - "stats" buffers are float[N][G][2] = {sum, sum of squares} over one (sample, group);
+ *     consumers turn them into mean / rstd themselves (count and eps are passed along).
+ */
+#ifndef PTI_VAE_H
+#define PTI_VAE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* pti_stream_t; /* hipStream_t */
+
+#define PTI_ABI_VERSION 1
+
+#define PTI_OK 0
+#define PTI_EINVAL (-1)   /* bad pointer / dimension */
+#define PTI_EUNSUPPORTED (-2) /* channel multiple / mode not built */
+#define PTI_ELAUNCH (-3)  /* hipGetLastError() after launch */
+
+/* input gather modes of the implicit-GEMM convolution */
+#define PTI_CONV_S1 0   /* stride 1, pad (k-1)/2              nn.Conv2d(k, s=1, p=k//2)              */
+#define PTI_CONV_S2PAD 1 /* F.pad(x,(0,1,0,1)) + 3x3 stride 2   MONAI AEKLDownsample                   */
+#define PTI_CONV_UP2 2  /* nearest 2x upsample then 3x3 s1 p1  MONAI Upsample(nontrainable)+postconv  */
+#define PTI_CONV_ZINS 3 /* zero-insert 2x, pad_lo 2: data-gradient of PTI_CONV_S2PAD                  */
+
+#define PTI_PRO_NONE 0
+#define PTI_PRO_GN 1      /* x -> GroupNorm affine                nn.GroupNorm                          */
+#define PTI_PRO_GN_SILU 2 /* x -> GroupNorm affine -> SiLU        nn.GroupNorm + F.silu (AEKLResBlock)  */
+
+typedef struct pti_conv_desc {
+  int32_t n, h, w, cin;   /* real input tensor [n,h,w,cin]                                   */
+  int32_t ho, wo, cout;   /* output tensor [n,ho,wo,cout]                                    */
+  int32_t ksize;          /* 1 or 3                                                          */
+  int32_t mode;           /* PTI_CONV_*                                                      */
+  int32_t prologue;       /* PTI_PRO_*: applied to the input while it is staged into LDS     */
+  int32_t groups;         /* GroupNorm groups of the prologue                                */
+  int32_t add_residual;   /* epilogue: y += residual (same shape as y)                       */
+  int32_t accum_stats;    /* epilogue: atomically add {sum,sumsq} of the stored y per        */
+                          /* (sample, out-group) into out_stats; out_groups below            */
+  int32_t out_groups;
+  float eps;              /* GroupNorm eps of the prologue                                   */
+  int32_t in_f32;         /* direct conv only: input is fp32 with explicit element strides   */
+  int32_t out_f32;        /* direct conv only: output is fp32 with explicit element strides  */
+  int64_t in_stride[4];   /* n,h,w,c element strides when in_f32 (else NHWC dense)           */
+  int64_t out_stride[4];  /* n,h,w,c element strides when out_f32                            */
+} pti_conv_desc;
+
+int pti_abi_version(void);
+const char* pti_last_error_string(void);
+
+/* ---- weights ------------------------------------------------------------------------- */
+/* Bytes of the MFMA-packed bf16 image of a [cout,cin,k,k] fp32 weight (0 if unsupported).  */
+int64_t pti_conv_packed_bytes(int cout, int cin, int ksize, int mode);
+/* Pack fp32 OIHW master weights (nn.Conv2d.weight / nn.Linear.weight layout) into the MFMA
+ * fragment order read by pti_conv2d_mfma.  transpose_flip=1 builds the data-gradient operand
+ * W'[ci][co][2-kh][2-kw]; cout/cin are those of the ORIGINAL weight.  nsrc>1 concatenates
+ * nsrc weights along the output channels (to_q/to_k/to_v fused into one 1x1).             */
+int pti_conv_pack_weights(const float* const* w_oihw, int nsrc, void* packed, int cout, int cin,
+                          int ksize, int mode, int transpose_flip, pti_stream_t s);
+
+/* ---- GroupNorm statistics (nn.GroupNorm's reduction) ---------------------------------- */
+/* stats[n][g] += {sum, sumsq} of x[n, :, channels of g]; stats must be zeroed by the caller. */
+int pti_gn_stats(const void* x_nhwc_bf16, float* stats, int n, int hw, int c, int groups,
+                 pti_stream_t s);
+
+/* ---- convolutions ---------------------------------------------------------------------- */
+/* Implicit-GEMM 3x3 / 1x1 convolution on bf16 MFMA (v_mfma_f32_32x32x16_bf16), fp32 accumulate:
+ * y = conv(prologue(x)) + bias [+ residual].  Replaces nn.Conv2d (+ the GroupNorm/SiLU in
+ * front of it, + the residual add behind it) inside MONAI AEKLResBlock / AEKLDownsample /
+ * Upsample / SABlock linears.  cin, cout multiples of 32.  in_stats: float[n][groups][2].  */
+int pti_conv2d_mfma(const void* x, const void* w_packed, const float* bias, const float* in_stats,
+                    const float* gamma, const float* beta, const void* residual, void* y,
+                    float* out_stats, const pti_conv_desc* d, pti_stream_t s);
+
+/* Direct (VALU, fp32 math) convolution for the degenerate-channel layers (cin or cout < 32):
+ * conv_in, conv_out of Encoder/Decoder.  w: fp32 [k*k][cin][cout]; see pti_conv_desc strides. */
+int pti_conv2d_direct(const void* x, const float* w_tck, const float* bias, const float* in_stats,
+                      const float* gamma, const float* beta, void* y, const pti_conv_desc* d,
+                      pti_stream_t s);
+
+/* Weight/bias gradient of pti_conv2d_direct (autograd of nn.Conv2d for the degenerate layers):
+ * dw[tap*st_tap + cw*st_cw + k*st_k] += sum_p narrow[p][k] * P(wide)[p + sgn*(tap offset)][cw]
+ * for every narrow channel k < cn; wide is dense NHWC bf16 with cw channels (prologue P optional),
+ * narrow is fp32/bf16 with element strides narrow_stride[n,h,w,c].  dbias_wide[cw] += column sums
+ * of wide, dbias_narrow[k] += sum of narrow (either may be NULL).  Accumulates with atomics.    */
+int pti_wgrad_direct(const void* wide, const void* narrow, float* dw, float* dbias_wide,
+                     float* dbias_narrow, const float* in_stats, const float* gamma,
+                     const float* beta, int n, int h, int w, int cw, int cn, int ksize, int sgn,
+                     int prologue, int groups, float eps, int narrow_f32,
+                     const int64_t* narrow_stride, int64_t dw_stride_tap, int64_t dw_stride_cw,
+                     int64_t dw_stride_k, pti_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTI_VAE_H */

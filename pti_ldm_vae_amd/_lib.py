@@ -1,0 +1,81 @@
+"""ctypes binding of ``libpti_vae_hip.so`` (C-ABI declared in ``include/pti_vae.h``).
+
+The product path has no CPU or PyTorch fallback: if the shared object is missing or a
+symbol cannot be resolved this module raises, loudly, at first use.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpti_vae_hip.so")
+
+PTI_CONV_S1, PTI_CONV_S2PAD, PTI_CONV_UP2, PTI_CONV_ZINS = 0, 1, 2, 3
+PTI_PRO_NONE, PTI_PRO_GN, PTI_PRO_GN_SILU = 0, 1, 2
+
+
+class ConvDesc(C.Structure):
+    """``pti_conv_desc`` of include/pti_vae.h (field order must match)."""
+
+    _fields_ = [
+        ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("cin", C.c_int32),
+        ("ho", C.c_int32), ("wo", C.c_int32), ("cout", C.c_int32),
+        ("ksize", C.c_int32), ("mode", C.c_int32), ("prologue", C.c_int32), ("groups", C.c_int32),
+        ("add_residual", C.c_int32), ("accum_stats", C.c_int32), ("out_groups", C.c_int32),
+        ("eps", C.c_float), ("in_f32", C.c_int32), ("out_f32", C.c_int32),
+        ("in_stride", C.c_int64 * 4), ("out_stride", C.c_int64 * 4),
+    ]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_I64 = C.c_int64
+_F = C.c_float
+
+# symbol -> (restype, argtypes); every symbol include/pti_vae.h declares is listed here and
+# tests/test_abi.py checks the two lists against each other.
+SIGNATURES = {
+    "pti_abi_version": (_I, []),
+    "pti_last_error_string": (C.c_char_p, []),
+    "pti_conv_packed_bytes": (_I64, [_I, _I, _I, _I]),
+    "pti_conv_pack_weights": (_I, [C.POINTER(_P), _I, _P, _I, _I, _I, _I, _I, _P]),
+    "pti_gn_stats": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "pti_conv2d_mfma": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(ConvDesc), _P]),
+    "pti_conv2d_direct": (_I, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(ConvDesc), _P]),
+    "pti_wgrad_direct": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I,
+                              C.POINTER(_I64), _I64, _I64, _I64, _P]),
+}
+
+_lib = None
+
+
+class PtiError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the shared library; raise if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PtiError(
+                f"{LIB_PATH} is missing: the HIP extension was not built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (or pti_ldm_vae_amd/csrc/build.sh). "
+                "There is no CPU/PyTorch fallback for the VAE hot path.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        ver = handle.pti_abi_version()
+        if ver != 1:
+            raise PtiError(f"libpti_vae_hip.so ABI version {ver}, expected 1")
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().pti_last_error_string()
+        raise PtiError(f"{what or 'pti call'} failed (code {rc}): {msg.decode() if msg else ''}")

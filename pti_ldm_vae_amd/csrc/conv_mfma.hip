@@ -1,0 +1,473 @@
+// Implicit-GEMM 3x3 / 1x1 convolution for gfx950 on v_mfma_f32_32x32x16_bf16.
+//
+// Replaces nn.Conv2d inside MONAI's AEKLResBlock / AEKLDownsample / Upsample / SABlock linears
+// (reference src/pti_ldm_vae/models/autoencoder.py:67-79 builds them),
+// with the GroupNorm-affine(+SiLU) that precedes each conv folded into the LDS loader, the
+// nearest-2x up-sample / asymmetric-pad stride-2 gather folded into the loader's addressing, and
+// bias + residual add + next-GroupNorm statistics folded into the epilogue.
+//
+// Layout: activations NHWC bf16.  One workgroup (256 threads = 4 waves) owns an 8x16 output-pixel
+// tile (M = 128 GEMM rows) x COUT_TILE output channels:
+//   * the input halo tile ((8-1)*S+K) x ((16-1)*S+K) pixels x CK channels is staged ONCE into LDS
+//     (16-byte pieces, XOR-swizzled by the halo column so ds_read_b128 is conflict free) and
+//     re-used by all K*K taps;
+//   * weights arrive pre-packed in MFMA-fragment order (pti_conv_pack_weights), streamed through a
+//     2-deep LDS ring in steps of WBLK k-blocks (16 input channels x COUT_TILE), prefetched into
+//     registers one step ahead;
+//   * MFMA orientation is D[cout][pixel] (A = weights, B = pixels) so each lane ends up with 4
+//     consecutive output channels of one pixel per accumulator quad -> 8-byte NHWC stores.
+#include "pti_common.h"
+
+namespace {
+
+constexpr int TH = 8, TW = 16;  // output tile (pixels)
+
+__host__ __device__ constexpr int pick_cout_tile(int cout) { return cout % 128 == 0 ? 128 : (cout % 64 == 0 ? 64 : 32); }
+__host__ __device__ constexpr int pick_ck(int cin, int stride2) {
+  int ck = cin % 128 == 0 ? 128 : (cin % 64 == 0 ? 64 : 32);
+  return (stride2 && ck > 64) ? 64 : ck;
+}
+// largest divisor of kbc with wblk*nt <= 16 (one weight step <= 16 KiB)
+__host__ __device__ constexpr int pick_wblk(int kbc, int nt) {
+  int best = 1;
+  for (int w = 1; w <= kbc; ++w)
+    if (kbc % w == 0 && w * nt <= 16) best = w;
+  return best;
+}
+
+template <int KS, int S, int CK, int COUT_TILE>
+struct Cfg {
+  static constexpr int HH = (TH - 1) * S + KS, HW = (TW - 1) * S + KS;
+  static constexpr int NP = HH * HW;        // halo pixels
+  static constexpr int NC = CK / 8;         // 16-byte pieces per pixel
+  static constexpr int PIXB = CK * 2;       // bytes per halo pixel
+  static constexpr int NT = COUT_TILE / 32; // 32-wide cout fragments per tile
+  static constexpr int KPC = CK / 16;       // k-blocks per tap
+  static constexpr int KBC = KS * KS * KPC; // k-blocks per cin chunk
+  static constexpr int WBLK = pick_wblk(KBC, NT);
+  static constexpr int NSTEP = KBC / WBLK;
+  static constexpr int STEPB = WBLK * NT * 1024;  // bytes per weight step
+  static constexpr int WM = (NT >= 2) ? 2 : 4, WN = 4 / WM;
+  static constexpr int PXF = 4 / WM;   // pixel fragments (32 px) per wave
+  static constexpr int CF = NT / WN;   // cout fragments per wave
+  static constexpr int HALO_BYTES = NP * PIXB;
+  static constexpr int LDS_BYTES = HALO_BYTES + 2 * STEPB;
+  static constexpr int KEY_SHIFT = (NC == 16) ? 0 : (NC == 8 ? 1 : 2);
+  static constexpr int WPIECES = (STEPB / 16 + 255) / 256;  // 16-byte pieces per thread per step
+  static constexpr int HITERS = (NP * NC + 255) / 256;
+};
+
+struct ConvArgs {
+  const bf16* x;
+  const unsigned char* w;
+  const float* bias;
+  const float* in_stats;
+  const float* gamma;
+  const float* beta;
+  const bf16* res;
+  bf16* y;
+  float* out_stats;
+  int N, H, W, Cin, Ho, Wo, Cout;
+  int mode, prologue, groups, out_groups;
+  float eps, inv_cnt;
+  int tiles_x, tiles_y;
+};
+
+template <int KS, int S, int CK, int COUT_TILE>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
+  using C = Cfg<KS, S, CK, COUT_TILE>;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS_BYTES];
+  unsigned char* halo = smem;
+  unsigned char* wbuf = smem + C::HALO_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hsel = lane >> 5;  // k-half selector of the MFMA operand maps
+  int t = blockIdx.x;
+  const int tile_x = t % a.tiles_x;
+  t /= a.tiles_x;
+  const int tile_y = t % a.tiles_y;
+  const int n = t / a.tiles_y;
+  const int oy0 = tile_y * TH, ox0 = tile_x * TW;
+  const int ct = blockIdx.y;
+  const int nchunks = a.Cin / CK;
+  const int wm = wave / C::WN, wn = wave % C::WN;
+
+  // virtual-input origin of the halo tile
+  const int pad_lo = (a.mode == PTI_CONV_S2PAD) ? 0 : (a.mode == PTI_CONV_ZINS ? 2 : (KS - 1) / 2);
+  const int vy0 = oy0 * S - pad_lo, vx0 = ox0 * S - pad_lo;
+  const bool twox = (a.mode == PTI_CONV_UP2) || (a.mode == PTI_CONV_ZINS);
+  const int VH = twox ? 2 * a.H : a.H, VW = twox ? 2 * a.W : a.W;
+
+  // ---- per-lane LDS read addresses of the pixel (B) fragments ----
+  int pbase[C::PXF][KS];
+  int tkey[KS];
+  {
+    const int j = lane & 31;
+    const int tx = j & 15;
+#pragma unroll
+    for (int kw = 0; kw < KS; ++kw) {
+      const int hx = tx * S + kw;
+      tkey[kw] = (hsel ^ ((hx >> C::KEY_SHIFT) & (C::NC - 1))) << 4;
+#pragma unroll
+      for (int i = 0; i < C::PXF; ++i) {
+        const int ty = 2 * (wm * C::PXF + i) + (j >> 4);
+        pbase[i][kw] = ((ty * S) * C::HW + hx) * C::PIXB;
+      }
+    }
+  }
+
+  f32x16 acc[C::PXF][C::CF];
+#pragma unroll
+  for (int i = 0; i < C::PXF; ++i)
+#pragma unroll
+    for (int c = 0; c < C::CF; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.f;
+
+  // ---- weight ring: step g of this (cout tile) lives at wsrc + g*STEPB ----
+  const unsigned char* wsrc = a.w + (size_t)ct * nchunks * C::NSTEP * C::STEPB;
+  const int total_steps = nchunks * C::NSTEP;
+  u32x4 wreg[C::WPIECES];
+  auto wload = [&](int g) {
+#pragma unroll
+    for (int k = 0; k < C::WPIECES; ++k) {
+      const int q = tid + k * 256;
+      if (q * 16 < C::STEPB) wreg[k] = *(const u32x4*)(wsrc + (size_t)g * C::STEPB + q * 16);
+    }
+  };
+  auto wstore = [&](int buf) {
+#pragma unroll
+    for (int k = 0; k < C::WPIECES; ++k) {
+      const int q = tid + k * 256;
+      if (q * 16 < C::STEPB) *(u32x4*)(wbuf + buf * C::STEPB + q * 16) = wreg[k];
+    }
+  };
+  wload(0);
+  wstore(0);
+
+  // ---- halo loader geometry (constant per thread) ----
+  const int lc = tid % C::NC;       // 16-byte piece (8 channels) within a pixel
+  const int lp0 = tid / C::NC;      // first halo pixel of this thread
+  constexpr int PSTEP = 256 / C::NC;
+  const int cpg = a.Cin / (a.groups > 0 ? a.groups : 1);
+
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    // ================= stage the halo tile of this cin chunk =================
+    float sc[8], sh[8];
+    if (a.prologue != PTI_PRO_NONE) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int ch = chunk * CK + lc * 8 + j;
+        const int g = ch / cpg;
+        const float sum = a.in_stats[(n * a.groups + g) * 2], sq = a.in_stats[(n * a.groups + g) * 2 + 1];
+        const float mean = sum * a.inv_cnt;
+        const float var = fmaxf(sq * a.inv_cnt - mean * mean, 0.f);
+        const float rstd = rsqrtf(var + a.eps);
+        sc[j] = rstd * a.gamma[ch];
+        sh[j] = a.beta[ch] - mean * sc[j];
+      }
+    }
+    u32x4 raw[C::HITERS];
+    bool ok[C::HITERS];
+#pragma unroll
+    for (int it = 0; it < C::HITERS; ++it) {
+      const int p = lp0 + it * PSTEP;
+      const int hy = p / C::HW, hx = p - hy * C::HW;
+      const int vy = vy0 + hy, vx = vx0 + hx;
+      bool v = (p < C::NP) && vy >= 0 && vy < VH && vx >= 0 && vx < VW;
+      int iy = vy, ix = vx;
+      if (twox) {
+        if (a.mode == PTI_CONV_ZINS) v = v && !((vy | vx) & 1);
+        iy = vy >> 1;
+        ix = vx >> 1;
+      }
+      ok[it] = v;
+      raw[it] = u32x4{0u, 0u, 0u, 0u};
+      if (v) raw[it] = *(const u32x4*)(a.x + ((size_t)(n * a.H + iy) * a.W + ix) * a.Cin + chunk * CK + lc * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < C::HITERS; ++it) {
+      const int p = lp0 + it * PSTEP;
+      if (p < C::NP) {
+        const int hy = p / C::HW, hx = p - hy * C::HW;
+        u32x4 r = raw[it];
+        if (a.prologue != PTI_PRO_NONE && ok[it]) {
+          float f[8];
+          unpack8(r, f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float v = f[j] * sc[j] + sh[j];
+            if (a.prologue == PTI_PRO_GN_SILU) v = silu_f(v);
+            f[j] = v;
+          }
+          r = pack8(f);
+        }
+        const int key = (hx >> C::KEY_SHIFT) & (C::NC - 1);
+        *(u32x4*)(halo + p * C::PIXB + ((lc ^ key) << 4)) = r;
+      }
+    }
+    __syncthreads();
+
+    // ================= MFMA main loop over the weight steps of this chunk =================
+#pragma unroll
+    for (int s = 0; s < C::NSTEP; ++s) {
+      const int g = chunk * C::NSTEP + s;
+      const bool more = (g + 1 < total_steps);
+      if (more) wload(g + 1);
+      const unsigned char* wcur = wbuf + (g & 1) * C::STEPB;
+#pragma unroll
+      for (int kbl = 0; kbl < C::WBLK; ++kbl) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int kb = s * C::WBLK + kbl;
+        const int tap = kb / C::KPC, kc = kb % C::KPC;
+        const int kh = tap / KS, kw = tap % KS;
+        bf16x8 bfrag[C::PXF], afrag[C::CF];
+#pragma unroll
+        for (int i = 0; i < C::PXF; ++i)
+          bfrag[i] = *(const bf16x8*)(halo + pbase[i][kw] + kh * C::HW * C::PIXB + ((kc * 32) ^ tkey[kw]));
+#pragma unroll
+        for (int c = 0; c < C::CF; ++c)
+          afrag[c] = *(const bf16x8*)(wcur + ((kbl * C::NT + wn * C::CF + c) * 64 + lane) * 16);
+#pragma unroll
+        for (int i = 0; i < C::PXF; ++i)
+#pragma unroll
+          for (int c = 0; c < C::CF; ++c)
+            acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[c], bfrag[i], acc[i][c], 0, 0, 0);
+      }
+      if (more) wstore((g + 1) & 1);
+      __syncthreads();
+    }
+  }
+
+  // ================= epilogue: bias, residual, store, optional GN statistics =================
+  const int j = lane & 31;
+  float* sstat = reinterpret_cast<float*>(smem);  // [out_groups][2], reuse of the (now idle) halo
+  const bool do_stats = a.out_stats != nullptr;
+  const int ocpg = do_stats ? a.Cout / a.out_groups : 1;
+  if (do_stats) {
+    if (tid < 2 * a.out_groups) sstat[tid] = 0.f;
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < C::PXF; ++i) {
+    const int ty = 2 * (wm * C::PXF + i) + (j >> 4), tx = j & 15;
+    const int oy = oy0 + ty, ox = ox0 + tx;
+    const bool inb = (oy < a.Ho) && (ox < a.Wo);
+    const size_t pix = ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.Cout;
+#pragma unroll
+    for (int c = 0; c < C::CF; ++c) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co = ct * COUT_TILE + (wn * C::CF + c) * 32 + 8 * q + 4 * hsel;
+        float v0 = acc[i][c][4 * q + 0], v1 = acc[i][c][4 * q + 1], v2 = acc[i][c][4 * q + 2],
+              v3 = acc[i][c][4 * q + 3];
+        if (a.bias) {
+          const f32x4 b = *(const f32x4*)(a.bias + co);
+          v0 += b[0]; v1 += b[1]; v2 += b[2]; v3 += b[3];
+        }
+        u32x2 packed = u32x2{0u, 0u};
+        if (inb) {
+          if (a.res) {
+            const u32x2 rr = *(const u32x2*)(a.res + pix + co);
+            v0 += __uint_as_float(rr[0] << 16);
+            v1 += __uint_as_float(rr[0] & 0xffff0000u);
+            v2 += __uint_as_float(rr[1] << 16);
+            v3 += __uint_as_float(rr[1] & 0xffff0000u);
+          }
+          packed = pack4(v0, v1, v2, v3);
+          *(u32x2*)(a.y + pix + co) = packed;
+        }
+        if (do_stats) {
+          // statistics of the values as stored (bf16-rounded), like a later read pass would see
+          float r0 = __uint_as_float(packed[0] << 16), r1 = __uint_as_float(packed[0] & 0xffff0000u);
+          float r2 = __uint_as_float(packed[1] << 16), r3 = __uint_as_float(packed[1] & 0xffff0000u);
+          if (!inb) r0 = r1 = r2 = r3 = 0.f;
+          if (ocpg >= 4) {
+            float s1 = (r0 + r1) + (r2 + r3), s2 = (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
+            // lanes 0..31 (and 32..63) of this quad hold 32 different pixels of the same 4 channels
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) {
+              s1 += __shfl_xor(s1, o, 64);
+              s2 += __shfl_xor(s2, o, 64);
+            }
+            if (j == 0) {
+              const int g = co / ocpg;
+              atomicAdd(&sstat[2 * g], s1);
+              atomicAdd(&sstat[2 * g + 1], s2);
+            }
+          } else {  // ocpg == 2: two groups inside the quad
+            float a1 = r0 + r1, a2 = r0 * r0 + r1 * r1, b1 = r2 + r3, b2 = r2 * r2 + r3 * r3;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) {
+              a1 += __shfl_xor(a1, o, 64);
+              a2 += __shfl_xor(a2, o, 64);
+              b1 += __shfl_xor(b1, o, 64);
+              b2 += __shfl_xor(b2, o, 64);
+            }
+            if (j == 0) {
+              const int g = co / 2;
+              atomicAdd(&sstat[2 * g], a1);
+              atomicAdd(&sstat[2 * g + 1], a2);
+              atomicAdd(&sstat[2 * g + 2], b1);
+              atomicAdd(&sstat[2 * g + 3], b2);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (do_stats) {
+    __syncthreads();
+    const int g0 = (ct * COUT_TILE) / ocpg, ng = COUT_TILE / ocpg;
+    if (tid < 2 * ng) atomicAdd(&a.out_stats[(n * a.out_groups + g0) * 2 + tid], sstat[2 * g0 + tid]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing: fp32 OIHW -> bf16 [cout tile][cin chunk][k-block][nt][lane][8]
+// ---------------------------------------------------------------------------------------------
+struct PackArgs {
+  const float* src[4];
+  int nsrc;
+  bf16* dst;
+  int cout_l, cin_l;   // logical (as seen by the consuming conv) channel counts
+  int cout_o, cin_o;   // original weight dims (per source)
+  int ks, ck, cout_tile, flip;
+  long long total;
+};
+
+__global__ void pack_weights_kernel(PackArgs p) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= p.total) return;
+  const int NT = p.cout_tile / 32, KPC = p.ck / 16, KBC = p.ks * p.ks * KPC, nch = p.cin_l / p.ck;
+  long long r = e;
+  const int j = r % 8; r /= 8;
+  const int lane = r % 64; r /= 64;
+  const int nt = r % NT; r /= NT;
+  const int kb = r % KBC; r /= KBC;
+  const int chunk = r % nch; r /= nch;
+  const int ct = (int)r;
+  const int co = ct * p.cout_tile + nt * 32 + (lane & 31);
+  const int tap = kb / KPC, kc = kb % KPC;
+  const int ci = chunk * p.ck + kc * 16 + 8 * (lane >> 5) + j;
+  const int kk = p.ks * p.ks;
+  float v;
+  if (!p.flip) {
+    const int s = co / p.cout_o, cs = co % p.cout_o;
+    v = p.src[s][((size_t)cs * p.cin_o + ci) * kk + tap];
+  } else {  // logical co is an original input channel, logical ci an original output channel
+    v = p.src[0][((size_t)ci * p.cin_o + co) * kk + (kk - 1 - tap)];
+  }
+  p.dst[e] = (bf16)v;
+}
+
+template <int KS, int S, int CK, int COUT_TILE>
+int launch_cfg(const ConvArgs& a, hipStream_t st) {
+  dim3 grid(a.N * a.tiles_x * a.tiles_y, a.Cout / COUT_TILE);
+  hipLaunchKernelGGL((conv_mfma_kernel<KS, S, CK, COUT_TILE>), grid, dim3(256), 0, st, a);
+  return 0;
+}
+
+template <int KS, int S, int CK>
+int launch_ct(const ConvArgs& a, int cout_tile, hipStream_t st) {
+  switch (cout_tile) {
+    case 128: return launch_cfg<KS, S, CK, 128>(a, st);
+    case 64: return launch_cfg<KS, S, CK, 64>(a, st);
+    default: return launch_cfg<KS, S, CK, 32>(a, st);
+  }
+}
+
+template <int KS, int S>
+int launch_ck(const ConvArgs& a, int ck, int cout_tile, hipStream_t st) {
+  switch (ck) {
+    case 128:
+      if constexpr (S == 1) return launch_ct<KS, S, 128>(a, cout_tile, st);
+      return -1;
+    case 64: return launch_ct<KS, S, 64>(a, cout_tile, st);
+    default: return launch_ct<KS, S, 32>(a, cout_tile, st);
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t pti_conv_packed_bytes(int cout, int cin, int ksize, int mode) {
+  (void)mode;
+  if (cout <= 0 || cin <= 0 || cout % 32 || cin % 32 || (ksize != 1 && ksize != 3)) return 0;
+  return (int64_t)2 * cout * cin * ksize * ksize;
+}
+
+extern "C" int pti_conv_pack_weights(const float* const* w, int nsrc, void* packed, int cout, int cin,
+                                     int ksize, int mode, int transpose_flip, pti_stream_t s) {
+  if (!w || !packed || nsrc < 1 || nsrc > 4) PTI_FAIL(PTI_EINVAL, "pack_weights: bad pointer/nsrc");
+  if (cout % 32 || cin % 32 || (ksize != 1 && ksize != 3))
+    PTI_FAIL(PTI_EUNSUPPORTED, "pack_weights: cout=%d cin=%d k=%d need multiples of 32, k in {1,3}", cout, cin, ksize);
+  if (transpose_flip && nsrc != 1) PTI_FAIL(PTI_EINVAL, "pack_weights: transpose_flip needs nsrc=1");
+  PackArgs p;
+  for (int i = 0; i < 4; ++i) p.src[i] = i < nsrc ? w[i] : nullptr;
+  p.nsrc = nsrc;
+  p.dst = (bf16*)packed;
+  p.cout_o = cout;
+  p.cin_o = cin;
+  p.cout_l = transpose_flip ? cin : cout * nsrc;
+  p.cin_l = transpose_flip ? cout : cin;
+  p.ks = ksize;
+  p.flip = transpose_flip;
+  p.cout_tile = pick_cout_tile(p.cout_l);
+  p.ck = pick_ck(p.cin_l, mode == PTI_CONV_S2PAD);
+  p.total = (long long)p.cout_l * p.cin_l * ksize * ksize;
+  const int blocks = (int)((p.total + 255) / 256);
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, p);
+  PTI_CHECK_LAUNCH("pack_weights");
+  return PTI_OK;
+}
+
+extern "C" int pti_conv2d_mfma(const void* x, const void* w_packed, const float* bias, const float* in_stats,
+                               const float* gamma, const float* beta, const void* residual, void* y,
+                               float* out_stats, const pti_conv_desc* d, pti_stream_t s) {
+  if (!x || !w_packed || !y || !d) PTI_FAIL(PTI_EINVAL, "conv2d_mfma: null pointer");
+  if (d->cin % 32 || d->cout % 32 || d->cin <= 0 || d->cout <= 0)
+    PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: cin=%d cout=%d must be positive multiples of 32", d->cin, d->cout);
+  if (d->ksize != 1 && d->ksize != 3) PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: ksize %d", d->ksize);
+  if (d->ksize == 1 && d->mode != PTI_CONV_S1) PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: 1x1 supports PTI_CONV_S1 only");
+  if (d->n <= 0 || d->h <= 0 || d->w <= 0) PTI_FAIL(PTI_EINVAL, "conv2d_mfma: bad dims");
+  int eho, ewo;
+  switch (d->mode) {
+    case PTI_CONV_S1: eho = d->h; ewo = d->w; break;
+    case PTI_CONV_S2PAD: eho = (d->h + 1 - 3) / 2 + 1; ewo = (d->w + 1 - 3) / 2 + 1; break;
+    case PTI_CONV_UP2: case PTI_CONV_ZINS: eho = 2 * d->h; ewo = 2 * d->w; break;
+    default: PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: mode %d", d->mode);
+  }
+  if (d->ho != eho || d->wo != ewo)
+    PTI_FAIL(PTI_EINVAL, "conv2d_mfma: output %dx%d does not match mode %d on %dx%d (want %dx%d)", d->ho, d->wo,
+             d->mode, d->h, d->w, eho, ewo);
+  if (d->prologue != PTI_PRO_NONE) {
+    if (!in_stats || !gamma || !beta || d->groups <= 0 || d->cin % d->groups)
+      PTI_FAIL(PTI_EINVAL, "conv2d_mfma: prologue needs stats/gamma/beta and groups | cin");
+  }
+  if (d->add_residual && !residual) PTI_FAIL(PTI_EINVAL, "conv2d_mfma: add_residual without residual");
+  if (d->accum_stats) {
+    if (!out_stats || d->out_groups <= 0 || d->cout % d->out_groups) PTI_FAIL(PTI_EINVAL, "conv2d_mfma: bad out stats");
+    const int ocpg = d->cout / d->out_groups;
+    if (ocpg != 2 && (ocpg % 4 != 0 || ocpg > 32)) PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: channels/group %d for fused stats", ocpg);
+    if (2 * d->out_groups > 256) PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: too many out groups");
+  }
+  ConvArgs a;
+  a.x = (const bf16*)x; a.w = (const unsigned char*)w_packed; a.bias = bias; a.in_stats = in_stats;
+  a.gamma = gamma; a.beta = beta; a.res = d->add_residual ? (const bf16*)residual : nullptr; a.y = (bf16*)y;
+  a.out_stats = d->accum_stats ? out_stats : nullptr;
+  a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Ho = d->ho; a.Wo = d->wo; a.Cout = d->cout;
+  a.mode = d->mode; a.prologue = d->prologue; a.groups = d->groups; a.out_groups = d->out_groups;
+  a.eps = d->eps;
+  a.inv_cnt = d->prologue != PTI_PRO_NONE ? 1.0f / ((float)(d->cin / d->groups) * (float)d->h * (float)d->w) : 0.f;
+  a.tiles_x = cdiv(d->wo, TW); a.tiles_y = cdiv(d->ho, TH);
+  const int cout_tile = pick_cout_tile(d->cout);
+  const int ck = pick_ck(d->cin, d->mode == PTI_CONV_S2PAD);
+  int rc;
+  if (d->ksize == 1) rc = launch_ck<1, 1>(a, ck, cout_tile, (hipStream_t)s);
+  else if (d->mode == PTI_CONV_S2PAD) rc = launch_ck<3, 2>(a, ck, cout_tile, (hipStream_t)s);
+  else rc = launch_ck<3, 1>(a, ck, cout_tile, (hipStream_t)s);
+  if (rc != 0) PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: no kernel for ck=%d cout_tile=%d", ck, cout_tile);
+  PTI_CHECK_LAUNCH("conv2d_mfma");
+  return PTI_OK;
+}

@@ -1,0 +1,78 @@
+// Shared device/host helpers for the gfx950 (CDNA4) kernels of libpti_vae_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/pti_vae.h"
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// ---- error plumbing (host) ------------------------------------------------------------------
+void pti_set_error(const char* fmt, ...);
+#define PTI_FAIL(code, ...)      \
+  do {                           \
+    pti_set_error(__VA_ARGS__);  \
+    return (code);               \
+  } while (0)
+#define PTI_CHECK_LAUNCH(name)                                             \
+  do {                                                                     \
+    hipError_t e__ = hipGetLastError();                                    \
+    if (e__ != hipSuccess)                                                 \
+      PTI_FAIL(PTI_ELAUNCH, "%s: launch failed: %s", name, hipGetErrorString(e__)); \
+  } while (0)
+
+// ---- device helpers -------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t lo16) { return __uint_as_float(lo16 << 16); }
+
+// unpack 8 bf16 (one 16-byte piece) to 8 floats
+__device__ __forceinline__ void unpack8(const u32x4& r, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __uint_as_float(r[i] << 16);
+    f[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u);
+  }
+}
+// pack 8 floats to 8 bf16 (round to nearest even via the hardware cvt)
+__device__ __forceinline__ u32x4 pack8(const float* f) {
+  u32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    bf16x2 p;
+    p[0] = (bf16)f[2 * i];
+    p[1] = (bf16)f[2 * i + 1];
+    r[i] = __builtin_bit_cast(uint32_t, p);
+  }
+  return r;
+}
+__device__ __forceinline__ u32x2 pack4(float a, float b, float c, float d) {
+  bf16x2 p0, p1;
+  p0[0] = (bf16)a; p0[1] = (bf16)b; p1[0] = (bf16)c; p1[1] = (bf16)d;
+  u32x2 r;
+  r[0] = __builtin_bit_cast(uint32_t, p0);
+  r[1] = __builtin_bit_cast(uint32_t, p1);
+  return r;
+}
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+// d silu(v)/dv = s*(1 + v*(1-s)), s = sigmoid(v)
+__device__ __forceinline__ float dsilu_f(float v) {
+  float s = 1.0f / (1.0f + __expf(-v));
+  return s * (1.0f + v * (1.0f - s));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
