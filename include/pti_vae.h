@@ -107,6 +107,66 @@ int pti_wgrad_direct(const void* wide, const void* narrow, float* dw, float* dbi
                      const int64_t* narrow_stride, int64_t dw_stride_tap, int64_t dw_stride_cw,
                      int64_t dw_stride_k, pti_stream_t s);
 
+/* ---- convolution weight gradient (autograd of nn.Conv2d, MFMA path) ----------------------- */
+int64_t pti_conv_wgrad_workspace_bytes(int cout, int cin, int ksize, int splits);
+/* dw[cout][cin][k][k] (fp32, OIHW) and dbias[cout] (=, or += when accumulate) from dy and the
+ * SAME x / prologue / mode the forward conv saw (prologue is recomputed in the loader).  Split-K
+ * partials go to `workspace` with plain stores and are summed in a fixed order (deterministic). */
+int pti_conv_wgrad_mfma(const void* x, const void* dy, const float* in_stats, const float* gamma,
+                        const float* beta, float* dw, float* dbias, void* workspace,
+                        int64_t workspace_bytes, int accumulate, const pti_conv_desc* d,
+                        pti_stream_t s);
+
+/* ---- GroupNorm(+SiLU) backward, 2x2 sum pool ---------------------------------------------- */
+/* dx = d/dx of act(GroupNorm(x)) given da (+ dres added), dgamma/dbeta += ; sums: zeroed float
+ * [n][c][2] scratch; stats as produced by pti_gn_stats on x.  (autograd of nn.GroupNorm+F.silu) */
+int pti_gn_bwd(const void* x, const void* da, const void* dres, void* dx, const float* stats,
+               const float* gamma, const float* beta, float* sums, float* dgamma, float* dbeta,
+               int n, int hw, int c, int groups, float eps, int silu, pti_stream_t s);
+/* y[n,h,w,c] = sum of the 2x2 block of x[n,2h,2w,c]: backward of nn.Upsample(nearest, 2x).     */
+int pti_pool2x2_sum(const void* x, void* y, int n, int h, int w, int c, pti_stream_t s);
+
+/* ---- mid-block self-attention (MONAI SpatialAttentionBlock -> SABlock, 1 head, dim = c) ------ */
+/* qkv: bf16 [b,l,3c] (q|k|v per token, from the fused to_q/to_k/to_v 1x1 conv); o: bf16 [b,l,c] =
+ * softmax(q k^T c^-0.5) v; lse2: fp32 [b,l] log2-sum-exp kept for the backward.  c in {64,128,256},
+ * l % 64 == 0.  The l x l matrix is never materialised.                                          */
+int pti_attention_fwd(const void* qkv, void* o, float* lse2, int b, int l, int c, pti_stream_t s);
+/* dqkv: bf16 [b,l,3c] gradient w.r.t. qkv given dout (bf16 [b,l,c]); delta: fp32 [b,l] scratch.   */
+int pti_attention_bwd(const void* qkv, const void* o, const void* dout, const float* lse2,
+                      float* delta, void* dqkv, int b, int l, int c, pti_stream_t s);
+
+/* ---- latent bottleneck (MONAI AutoencoderKL.encode tail / sampling / post_quant_conv) ------- */
+/* h: fp32 [b,hw,l] (NHWC); eps/mu/sigma/logvar: fp32 [b,l,hw] (NCHW); zq: fp32 [b,hw,l].
+ * eps NULL => deterministic z = mu.  Weights are the nn.Conv2d 1x1 masters [l][l], biases [l]. */
+int pti_latent_head_fwd(const float* h, const float* eps, const float* wm, const float* bm,
+                        const float* wl, const float* bl, const float* wp, const float* bp,
+                        float* mu, float* sigma, float* logvar, float* zq, int b, int hw, int l,
+                        pti_stream_t s);
+int pti_post_quant(const float* z_nchw, const float* wp, const float* bp, float* zq_nhwc, int b,
+                   int hw, int l, pti_stream_t s);
+int pti_latent_head_bwd(const float* h, const float* eps, const float* wm, const float* bm,
+                        const float* wl, const float* bl, const float* wp, const float* bp,
+                        const float* dzq, const float* dmu, const float* dsigma, float* dh,
+                        float* gwm, float* gbm, float* gwl, float* gbl, float* gwp, float* gbp,
+                        int b, int hw, int l, pti_stream_t s);
+
+/* ---- loss step (reference src/pti_ldm_vae/models/losses.py:25-30,62-66; train_vae.py:393-394) */
+/* out2[0] += mean recon loss (L1, or L2 when l2), out2[1] += mean_b KL; d_* receive the gradient
+ * of recon + kl_weight*kl (NULL to skip).  third_mode 0: third used as log-variance (the
+ * reference call site); 1: third is sigma, input_is_logvar=False semantics.                    */
+int pti_vae_loss(const float* recon, const float* images, int64_t npix, const float* mu,
+                 const float* third, int64_t nlat, int batch, float* out2, float* d_recon,
+                 float* d_mu, float* d_third, int l2, int third_mode, float kl_weight,
+                 pti_stream_t s);
+
+/* ---- optimiser (torch.optim.Adam defaults, train_vae.py:301) on a flat fp32 arena ----------- */
+int pti_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                  float beta2, float eps, int step, float grad_scale, pti_stream_t s);
+
+/* ---- layout casts at the model boundary ------------------------------------------------------ */
+int pti_cast_nchw_f32_to_nhwc_bf16(const float* x, void* y, int n, int c, int hw, pti_stream_t s);
+int pti_cast_nhwc_bf16_to_nchw_f32(const void* x, float* y, int n, int c, int hw, pti_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,6 +45,19 @@ SIGNATURES = {
     "pti_conv2d_direct": (_I, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(ConvDesc), _P]),
     "pti_wgrad_direct": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I,
                               C.POINTER(_I64), _I64, _I64, _I64, _P]),
+    "pti_conv_wgrad_workspace_bytes": (_I64, [_I, _I, _I, _I]),
+    "pti_conv_wgrad_mfma": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I, C.POINTER(ConvDesc), _P]),
+    "pti_gn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
+    "pti_pool2x2_sum": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "pti_attention_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "pti_attention_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "pti_latent_head_fwd": (_I, [_P] * 12 + [_I, _I, _I, _P]),
+    "pti_post_quant": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "pti_latent_head_bwd": (_I, [_P] * 18 + [_I, _I, _I, _P]),
+    "pti_vae_loss": (_I, [_P, _P, _I64, _P, _P, _I64, _I, _P, _P, _P, _P, _I, _I, _F, _P]),
+    "pti_adam_step": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I, _F, _P]),
+    "pti_cast_nchw_f32_to_nhwc_bf16": (_I, [_P, _P, _I, _I, _I, _P]),
+    "pti_cast_nhwc_bf16_to_nchw_f32": (_I, [_P, _P, _I, _I, _I, _P]),
 }
 
 _lib = None

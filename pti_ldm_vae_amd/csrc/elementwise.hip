@@ -1,0 +1,326 @@
+// Small fused kernels around the latent bottleneck and the optimiser step (gfx950).
+//
+//  * pti_latent_head_fwd/bwd: MONAI AutoencoderKL.encode tail + sampling + post_quant_conv
+//      mu = quant_conv_mu(h); lv = clamp(quant_conv_log_sigma(h), -30, 20); sigma = exp(lv/2)
+//      z = mu + eps*sigma; zq = post_quant_conv(z)          
+//    three 1x1 convs on <=16 channels + clamp + exp + FMA collapse into one elementwise kernel.
+//  * pti_vae_loss: reconstruction (L1|L2 mean) + KL exactly as reference
+//      src/pti_ldm_vae/models/losses.py:25-30 / vae_scripts/train_vae.py:393-394, producing the loss
+//      scalars and the gradient seeds d(recon), d(mu), d(third) of  recon + kl_weight*kl  in one pass.
+//  * pti_adam_step: torch.optim.Adam (train_vae.py:301, defaults) on the flat fp32 parameter arena.
+#include "pti_common.h"
+
+namespace {
+
+constexpr int MAXL = 16;
+
+struct LatArgs {
+  const float* h;        // [B,HW,L] fp32 (NHWC)
+  const float* eps;      // [B,L,HW] fp32 (NCHW) or null (=> z = mu)
+  const float* wm; const float* bm; const float* wl; const float* bl; const float* wp; const float* bp;  // [L][L], [L]
+  float* mu; float* sigma; float* logvar;   // [B,L,HW] fp32 (NCHW); logvar may be null
+  float* zq;             // [B,HW,L] fp32 (NHWC)
+  int B, HW, L;
+};
+
+__global__ __launch_bounds__(256) void latent_fwd_kernel(LatArgs a) {
+  const long long total = (long long)a.B * a.HW;
+  const int L = a.L;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int p = e % a.HW;
+    const int b = e / a.HW;
+    float hv[MAXL], z[MAXL];
+#pragma unroll
+    for (int j = 0; j < MAXL; ++j) hv[j] = (j < L) ? a.h[e * L + j] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXL; ++i) {
+      if (i < L) {
+        float m = a.bm[i], l = a.bl[i];
+#pragma unroll
+        for (int j = 0; j < MAXL; ++j)
+          if (j < L) {
+            m += a.wm[i * L + j] * hv[j];
+            l += a.wl[i * L + j] * hv[j];
+          }
+        l = fminf(fmaxf(l, -30.f), 20.f);
+        const float sg = expf(0.5f * l);
+        const size_t o = ((size_t)b * L + i) * a.HW + p;
+        a.mu[o] = m;
+        a.sigma[o] = sg;
+        if (a.logvar) a.logvar[o] = l;
+        z[i] = a.eps ? m + a.eps[o] * sg : m;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXL; ++i) {
+      if (i < L) {
+        float v = a.bp[i];
+#pragma unroll
+        for (int j = 0; j < MAXL; ++j)
+          if (j < L) v += a.wp[i * L + j] * z[j];
+        a.zq[e * L + i] = v;
+      }
+    }
+  }
+}
+
+// decode-only entry: zq = post_quant_conv(z) for a user-supplied z (NCHW fp32)
+__global__ __launch_bounds__(256) void post_quant_kernel(const float* z, const float* wp, const float* bp, float* zq,
+                                                         int B, int HW, int L) {
+  const long long total = (long long)B * HW;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int p = e % HW;
+    const int b = e / HW;
+    for (int i = 0; i < L; ++i) {
+      float v = bp[i];
+      for (int j = 0; j < L; ++j) v += wp[i * L + j] * z[((size_t)b * L + j) * HW + p];
+      zq[e * L + i] = v;
+    }
+  }
+}
+
+struct LatBwdArgs {
+  const float* h; const float* eps;
+  const float* wm; const float* bm; const float* wl; const float* bl; const float* wp; const float* bp;
+  const float* dzq;      // [B,HW,L] NHWC fp32 or null
+  const float* dmu;      // [B,L,HW] NCHW fp32 or null   (external gradient on mu)
+  const float* dsigma;   // [B,L,HW] NCHW fp32 or null   (external gradient on sigma)
+  float* dh;             // [B,HW,L]
+  float* gwm; float* gbm; float* gwl; float* gbl; float* gwp; float* gbp;  // accumulated (atomics)
+  int B, HW, L;
+};
+
+__global__ __launch_bounds__(256) void latent_bwd_kernel(LatBwdArgs a) {
+  extern __shared__ float sm[];  // 3*(L*L+L)
+  const int L = a.L, LL = L * L + L;
+  for (int i = threadIdx.x; i < 3 * LL; i += 256) sm[i] = 0.f;
+  __syncthreads();
+  float* s_wm = sm; float* s_bm = sm + L * L;
+  float* s_wl = sm + LL; float* s_bl = s_wl + L * L;
+  float* s_wp = sm + 2 * LL; float* s_bp = s_wp + L * L;
+  const long long total = (long long)a.B * a.HW;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int p = e % a.HW;
+    const int b = e / a.HW;
+    float hv[MAXL], z[MAXL], sg[MAXL], ep[MAXL], dz[MAXL], dm[MAXL], dl[MAXL];
+    bool inr[MAXL];
+    for (int j = 0; j < L; ++j) hv[j] = a.h[e * L + j];
+    for (int i = 0; i < L; ++i) {
+      float m = a.bm[i], l = a.bl[i];
+      for (int j = 0; j < L; ++j) {
+        m += a.wm[i * L + j] * hv[j];
+        l += a.wl[i * L + j] * hv[j];
+      }
+      inr[i] = (l >= -30.f) && (l <= 20.f);   // torch.clamp passes the gradient on the closed range
+      l = fminf(fmaxf(l, -30.f), 20.f);
+      sg[i] = expf(0.5f * l);
+      const size_t o = ((size_t)b * L + i) * a.HW + p;
+      ep[i] = a.eps ? a.eps[o] : 0.f;
+      z[i] = m + ep[i] * sg[i];
+    }
+    for (int j = 0; j < L; ++j) {
+      float v = 0.f;
+      if (a.dzq)
+        for (int i = 0; i < L; ++i) v += a.wp[i * L + j] * a.dzq[e * L + i];
+      dz[j] = v;
+    }
+    if (a.dzq) {
+      for (int i = 0; i < L; ++i) {
+        const float g = a.dzq[e * L + i];
+        atomicAdd(&s_bp[i], g);
+        for (int j = 0; j < L; ++j) atomicAdd(&s_wp[i * L + j], g * z[j]);
+      }
+    }
+    for (int i = 0; i < L; ++i) {
+      const size_t o = ((size_t)b * L + i) * a.HW + p;
+      dm[i] = dz[i] + (a.dmu ? a.dmu[o] : 0.f);
+      const float dsg = dz[i] * ep[i] + (a.dsigma ? a.dsigma[o] : 0.f);
+      dl[i] = inr[i] ? dsg * sg[i] * 0.5f : 0.f;
+      atomicAdd(&s_bm[i], dm[i]);
+      atomicAdd(&s_bl[i], dl[i]);
+      for (int j = 0; j < L; ++j) {
+        atomicAdd(&s_wm[i * L + j], dm[i] * hv[j]);
+        atomicAdd(&s_wl[i * L + j], dl[i] * hv[j]);
+      }
+    }
+    for (int j = 0; j < L; ++j) {
+      float v = 0.f;
+      for (int i = 0; i < L; ++i) v += a.wm[i * L + j] * dm[i] + a.wl[i * L + j] * dl[i];
+      a.dh[e * L + j] = v;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < L * L; i += 256) {
+    atomicAdd(&a.gwm[i], s_wm[i]);
+    atomicAdd(&a.gwl[i], s_wl[i]);
+    atomicAdd(&a.gwp[i], s_wp[i]);
+  }
+  for (int i = threadIdx.x; i < L; i += 256) {
+    atomicAdd(&a.gbm[i], s_bm[i]);
+    atomicAdd(&a.gbl[i], s_bl[i]);
+    atomicAdd(&a.gbp[i], s_bp[i]);
+  }
+}
+
+// ---- loss -------------------------------------------------------------------------------------
+// out[0] += sum |r-x| or (r-x)^2 ; out[1] += sum_kl ; gradient seeds written scaled so that
+// d(total)/d(.) with total = mean_recon + kl_weight * mean_b(kl)  (losses.py:62-66 with the other
+// weights zero).  third_mode 0: third is used as log-variance (the reference call, train_vae.py:394);
+// 1: third is sigma with input_is_logvar=False (losses.py:25-26).
+__global__ __launch_bounds__(256) void vae_loss_kernel(const float* __restrict__ recon, const float* __restrict__ img,
+                                                       long long npix, const float* __restrict__ mu,
+                                                       const float* __restrict__ third, long long nlat, float* out,
+                                                       float* d_recon, float* d_mu, float* d_third, int l2,
+                                                       int third_mode, float kl_weight, float inv_npix, float inv_b) {
+  float sr = 0.f, sk = 0.f;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < npix; e += stride) {
+    const float d = recon[e] - img[e];
+    if (l2) {
+      sr += d * d;
+      if (d_recon) d_recon[e] = 2.f * d * inv_npix;
+    } else {
+      sr += fabsf(d);
+      if (d_recon) d_recon[e] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * inv_npix;
+    }
+  }
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < nlat; e += stride) {
+    const float m = mu[e], t = third[e];
+    float s = t, dsdt = 1.f;
+    if (third_mode == 1) {
+      s = logf(t * t + 1e-8f);
+      dsdt = 2.f * t / (t * t + 1e-8f);
+    }
+    const float es = expf(s);
+    sk += -0.5f * (1.f + s - m * m - es);
+    if (d_mu) d_mu[e] = kl_weight * inv_b * m;
+    if (d_third) d_third[e] = kl_weight * inv_b * (-0.5f * (1.f - es)) * dsdt;
+  }
+  sr = wave_sum(sr);
+  sk = wave_sum(sk);
+  __shared__ float red[8];
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[wave] = sr; red[4 + wave] = sk; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&out[0], (red[0] + red[1] + red[2] + red[3]) * inv_npix);
+    atomicAdd(&out[1], (red[4] + red[5] + red[6] + red[7]) * inv_b);
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long long n,
+                                                   float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt,
+                                                   float grad_scale) {
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+    const float gr = g[e] * grad_scale;
+    const float mm = b1 * m[e] + (1.f - b1) * gr;
+    const float vv = b2 * v[e] + (1.f - b2) * gr * gr;
+    m[e] = mm;
+    v[e] = vv;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    p[e] -= (lr / bc1) * (mm / denom);
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_nchw_f32_to_nhwc_bf16(const float* __restrict__ x, bf16* __restrict__ y,
+                                                                  int N, int C, int HW) {
+  const long long total = (long long)N * C * HW;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int c = e % C;
+    const long long t = e / C;
+    const int p = t % HW;
+    const int n = t / HW;
+    y[e] = (bf16)x[((size_t)n * C + c) * HW + p];
+  }
+}
+__global__ __launch_bounds__(256) void cast_nhwc_bf16_to_nchw_f32(const bf16* __restrict__ x, float* __restrict__ y,
+                                                                  int N, int C, int HW) {
+  const long long total = (long long)N * C * HW;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int p = e % HW;
+    const long long t = e / HW;
+    const int c = t % C;
+    const int n = t / C;
+    y[e] = (float)x[((size_t)n * HW + p) * C + c];
+  }
+}
+
+inline unsigned nblocks(long long total, int cap = 4096) {
+  long long b = (total + 255) / 256;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int pti_latent_head_fwd(const float* h, const float* eps, const float* wm, const float* bm,
+                                   const float* wl, const float* bl, const float* wp, const float* bp, float* mu,
+                                   float* sigma, float* logvar, float* zq, int b, int hw, int l, pti_stream_t s) {
+  if (!h || !wm || !bm || !wl || !bl || !wp || !bp || !mu || !sigma || !zq) PTI_FAIL(PTI_EINVAL, "latent_head_fwd: null pointer");
+  if (l <= 0 || l > MAXL || b <= 0 || hw <= 0) PTI_FAIL(PTI_EUNSUPPORTED, "latent_head_fwd: latent channels %d (max %d)", l, MAXL);
+  LatArgs a{h, eps, wm, bm, wl, bl, wp, bp, mu, sigma, logvar, zq, b, hw, l};
+  hipLaunchKernelGGL(latent_fwd_kernel, dim3(nblocks((long long)b * hw)), dim3(256), 0, (hipStream_t)s, a);
+  PTI_CHECK_LAUNCH("latent_head_fwd");
+  return PTI_OK;
+}
+
+extern "C" int pti_post_quant(const float* z_nchw, const float* wp, const float* bp, float* zq_nhwc, int b, int hw,
+                              int l, pti_stream_t s) {
+  if (!z_nchw || !wp || !bp || !zq_nhwc || l <= 0 || l > MAXL) PTI_FAIL(PTI_EINVAL, "post_quant: bad args");
+  hipLaunchKernelGGL(post_quant_kernel, dim3(nblocks((long long)b * hw)), dim3(256), 0, (hipStream_t)s, z_nchw, wp, bp,
+                     zq_nhwc, b, hw, l);
+  PTI_CHECK_LAUNCH("post_quant");
+  return PTI_OK;
+}
+
+extern "C" int pti_latent_head_bwd(const float* h, const float* eps, const float* wm, const float* bm,
+                                   const float* wl, const float* bl, const float* wp, const float* bp,
+                                   const float* dzq, const float* dmu, const float* dsigma, float* dh, float* gwm,
+                                   float* gbm, float* gwl, float* gbl, float* gwp, float* gbp, int b, int hw, int l,
+                                   pti_stream_t s) {
+  if (!h || !wm || !bm || !wl || !bl || !wp || !bp || !dh || !gwm || !gbm || !gwl || !gbl || !gwp || !gbp)
+    PTI_FAIL(PTI_EINVAL, "latent_head_bwd: null pointer");
+  if (l <= 0 || l > MAXL) PTI_FAIL(PTI_EUNSUPPORTED, "latent_head_bwd: latent channels %d", l);
+  LatBwdArgs a{h, eps, wm, bm, wl, bl, wp, bp, dzq, dmu, dsigma, dh, gwm, gbm, gwl, gbl, gwp, gbp, b, hw, l};
+  hipLaunchKernelGGL(latent_bwd_kernel, dim3(nblocks((long long)b * hw, 256)), dim3(256), 3 * (l * l + l) * sizeof(float),
+                     (hipStream_t)s, a);
+  PTI_CHECK_LAUNCH("latent_head_bwd");
+  return PTI_OK;
+}
+
+extern "C" int pti_vae_loss(const float* recon, const float* images, int64_t npix, const float* mu,
+                            const float* third, int64_t nlat, int batch, float* out2, float* d_recon, float* d_mu,
+                            float* d_third, int l2, int third_mode, float kl_weight, pti_stream_t s) {
+  if (!recon || !images || !mu || !third || !out2 || npix <= 0 || nlat <= 0 || batch <= 0) PTI_FAIL(PTI_EINVAL, "vae_loss: bad args");
+  hipLaunchKernelGGL(vae_loss_kernel, dim3(nblocks(npix, 1024)), dim3(256), 0, (hipStream_t)s, recon, images,
+                     (long long)npix, mu, third, (long long)nlat, out2, d_recon, d_mu, d_third, l2, third_mode, kl_weight,
+                     1.0f / (float)npix, 1.0f / (float)batch);
+  PTI_CHECK_LAUNCH("vae_loss");
+  return PTI_OK;
+}
+
+extern "C" int pti_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                             float beta2, float eps, int step, float grad_scale, pti_stream_t s) {
+  if (!p || !g || !m || !v || n <= 0 || step < 1) PTI_FAIL(PTI_EINVAL, "adam_step: bad args");
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adam_kernel, dim3(nblocks(n, 2048)), dim3(256), 0, (hipStream_t)s, p, g, m, v, (long long)n, lr, beta1,
+                     beta2, eps, bc1, bc2s, grad_scale);
+  PTI_CHECK_LAUNCH("adam_step");
+  return PTI_OK;
+}
+
+extern "C" int pti_cast_nchw_f32_to_nhwc_bf16(const float* x, void* y, int n, int c, int hw, pti_stream_t s) {
+  if (!x || !y) PTI_FAIL(PTI_EINVAL, "cast: null");
+  hipLaunchKernelGGL(cast_nchw_f32_to_nhwc_bf16, dim3(nblocks((long long)n * c * hw)), dim3(256), 0, (hipStream_t)s, x, (bf16*)y, n, c, hw);
+  PTI_CHECK_LAUNCH("cast_nchw_f32_to_nhwc_bf16");
+  return PTI_OK;
+}
+extern "C" int pti_cast_nhwc_bf16_to_nchw_f32(const void* x, float* y, int n, int c, int hw, pti_stream_t s) {
+  if (!x || !y) PTI_FAIL(PTI_EINVAL, "cast: null");
+  hipLaunchKernelGGL(cast_nhwc_bf16_to_nchw_f32, dim3(nblocks((long long)n * c * hw)), dim3(256), 0, (hipStream_t)s, (const bf16*)x, y, n, c, hw);
+  PTI_CHECK_LAUNCH("cast_nhwc_bf16_to_nchw_f32");
+  return PTI_OK;
+}

@@ -92,3 +92,173 @@ extern "C" int pti_gn_stats(const void* x, float* stats, int n, int hw, int c, i
   PTI_CHECK_LAUNCH("gn_stats");
   return PTI_OK;
 }
+
+// =============================================================================================
+// Backward of  a = act(GroupNorm(x))  (act = SiLU or identity), NHWC bf16.
+//   pass 1 (gn_bwd_reduce): per (sample, channel)  S1 = sum dy, S2 = sum dy*xhat  with
+//           dy = dA * act'(y); also accumulates dbeta += S1, dgamma += S2 (atomics).
+//   pass 2 (gn_bwd_apply):  dx = rstd*(gamma*dy - c1 - xhat*c2) [+ dres],  c1/c2 = group means of
+//           gamma*dy and gamma*dy*xhat built from S1/S2.
+// =============================================================================================
+namespace {
+
+struct GnbArgs {
+  const bf16* x; const bf16* da; const bf16* dres; bf16* dx;
+  const float* stats; const float* gamma; const float* beta;
+  float* sums;   // [N][C][2]
+  float* dgamma; float* dbeta;
+  int HW, C, G, silu, ppb;
+  float eps, inv_cnt;
+};
+
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnbArgs a) {
+  extern __shared__ float sm[];  // [C][2]
+  const int n = blockIdx.y, tid = threadIdx.x;
+  const int NC = a.C / 8, ppi = 256 / NC, lc = tid % NC, lp = tid / NC;
+  for (int i = tid; i < 2 * a.C; i += 256) sm[i] = 0.f;
+  __syncthreads();
+  const int cpg = a.C / a.G;
+  float sc[8], sh[8], mu[8], rs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ch = lc * 8 + j, g = ch / cpg;
+    const float sum = a.stats[(n * a.G + g) * 2], sq = a.stats[(n * a.G + g) * 2 + 1];
+    const float mean = sum * a.inv_cnt;
+    const float rstd = rsqrtf(fmaxf(sq * a.inv_cnt - mean * mean, 0.f) + a.eps);
+    mu[j] = mean; rs[j] = rstd;
+    sc[j] = rstd * a.gamma[ch];
+    sh[j] = a.beta[ch] - mean * sc[j];
+  }
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+  const int p0 = blockIdx.x * a.ppb, p1 = min(p0 + a.ppb, a.HW);
+  const size_t base = (size_t)n * a.HW * a.C + lc * 8;
+  for (int p = p0 + lp; p < p1; p += ppi) {
+    float fx[8], fd[8];
+    unpack8(*(const u32x4*)(a.x + base + (size_t)p * a.C), fx);
+    unpack8(*(const u32x4*)(a.da + base + (size_t)p * a.C), fd);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float dy = fd[j];
+      if (a.silu) dy *= dsilu_f(fx[j] * sc[j] + sh[j]);
+      s1[j] += dy;
+      s2[j] += dy * (fx[j] - mu[j]) * rs[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    atomicAdd(&sm[(lc * 8 + j) * 2], s1[j]);
+    atomicAdd(&sm[(lc * 8 + j) * 2 + 1], s2[j]);
+  }
+  __syncthreads();
+  for (int i = tid; i < a.C; i += 256) {
+    const float v1 = sm[2 * i], v2 = sm[2 * i + 1];
+    atomicAdd(&a.sums[((size_t)n * a.C + i) * 2], v1);
+    atomicAdd(&a.sums[((size_t)n * a.C + i) * 2 + 1], v2);
+    if (a.dbeta) atomicAdd(&a.dbeta[i], v1);
+    if (a.dgamma) atomicAdd(&a.dgamma[i], v2);
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnbArgs a) {
+  const int n = blockIdx.y, tid = threadIdx.x;
+  const int NC = a.C / 8, ppi = 256 / NC, lc = tid % NC, lp = tid / NC;
+  const int cpg = a.C / a.G;
+  float sc[8], sh[8], mu[8], rs[8], ga[8], c1[8], c2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ch = lc * 8 + j, g = ch / cpg;
+    const float sum = a.stats[(n * a.G + g) * 2], sq = a.stats[(n * a.G + g) * 2 + 1];
+    const float mean = sum * a.inv_cnt;
+    const float rstd = rsqrtf(fmaxf(sq * a.inv_cnt - mean * mean, 0.f) + a.eps);
+    mu[j] = mean; rs[j] = rstd; ga[j] = a.gamma[ch];
+    sc[j] = rstd * ga[j];
+    sh[j] = a.beta[ch] - mean * sc[j];
+    float t1 = 0.f, t2 = 0.f;
+    for (int cc = g * cpg; cc < (g + 1) * cpg; ++cc) {
+      const float gm = a.gamma[cc];
+      t1 += gm * a.sums[((size_t)n * a.C + cc) * 2];
+      t2 += gm * a.sums[((size_t)n * a.C + cc) * 2 + 1];
+    }
+    c1[j] = t1 * a.inv_cnt;
+    c2[j] = t2 * a.inv_cnt;
+  }
+  const int p0 = blockIdx.x * a.ppb, p1 = min(p0 + a.ppb, a.HW);
+  const size_t base = (size_t)n * a.HW * a.C + lc * 8;
+  for (int p = p0 + lp; p < p1; p += ppi) {
+    float fx[8], fd[8], fr[8];
+    unpack8(*(const u32x4*)(a.x + base + (size_t)p * a.C), fx);
+    unpack8(*(const u32x4*)(a.da + base + (size_t)p * a.C), fd);
+    if (a.dres) unpack8(*(const u32x4*)(a.dres + base + (size_t)p * a.C), fr);
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float dy = fd[j];
+      if (a.silu) dy *= dsilu_f(fx[j] * sc[j] + sh[j]);
+      const float xh = (fx[j] - mu[j]) * rs[j];
+      float v = rs[j] * (ga[j] * dy - c1[j] - xh * c2[j]);
+      if (a.dres) v += fr[j];
+      o[j] = v;
+    }
+    *(u32x4*)(a.dx + base + (size_t)p * a.C) = pack8(o);
+  }
+}
+
+// 2x2 sum pooling (backward of nearest 2x up-sampling): y[n,h,w,c] = sum of x[n,2h+{0,1},2w+{0,1},c]
+__global__ __launch_bounds__(256) void pool2x2_sum_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, int N,
+                                                          int H, int W, int C) {
+  const int NC = C / 8;
+  const long long total = (long long)N * H * W * NC;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int lc = e % NC;
+    long long p = e / NC;
+    const int w = p % W; p /= W;
+    const int h = p % H;
+    const int n = p / H;
+    const bf16* src = x + (((size_t)n * 2 * H + 2 * h) * 2 * W + 2 * w) * C + lc * 8;
+    float f0[8], f1[8], f2[8], f3[8], o[8];
+    unpack8(*(const u32x4*)(src), f0);
+    unpack8(*(const u32x4*)(src + C), f1);
+    unpack8(*(const u32x4*)(src + (size_t)2 * W * C), f2);
+    unpack8(*(const u32x4*)(src + (size_t)2 * W * C + C), f3);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (f0[j] + f1[j]) + (f2[j] + f3[j]);
+    *(u32x4*)(y + (((size_t)n * H + h) * W + w) * C + lc * 8) = pack8(o);
+  }
+}
+
+}  // namespace
+
+extern "C" int pti_gn_bwd(const void* x, const void* da, const void* dres, void* dx, const float* stats,
+                          const float* gamma, const float* beta, float* sums, float* dgamma, float* dbeta, int n,
+                          int hw, int c, int groups, float eps, int silu, pti_stream_t s) {
+  if (!x || !da || !dx || !stats || !gamma || !beta || !sums) PTI_FAIL(PTI_EINVAL, "gn_bwd: null pointer");
+  if (c < 8 || c > 2048 || (c & (c - 1)) || groups <= 0 || c % groups) PTI_FAIL(PTI_EUNSUPPORTED, "gn_bwd: c=%d groups=%d", c, groups);
+  GnbArgs a;
+  a.x = (const bf16*)x; a.da = (const bf16*)da; a.dres = (const bf16*)dres; a.dx = (bf16*)dx;
+  a.stats = stats; a.gamma = gamma; a.beta = beta; a.sums = sums; a.dgamma = dgamma; a.dbeta = dbeta;
+  a.HW = hw; a.C = c; a.G = groups; a.silu = silu; a.eps = eps;
+  a.inv_cnt = 1.0f / ((float)(c / groups) * (float)hw);
+  const int ppi = 256 / (c / 8);
+  int bps = cdiv(2048, n);
+  int ppb = cdiv(hw, bps);
+  ppb = cdiv(ppb, ppi) * ppi;
+  bps = cdiv(hw, ppb);
+  a.ppb = ppb;
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(bps, n), dim3(256), 2 * c * sizeof(float), (hipStream_t)s, a);
+  PTI_CHECK_LAUNCH("gn_bwd_reduce");
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(bps, n), dim3(256), 0, (hipStream_t)s, a);
+  PTI_CHECK_LAUNCH("gn_bwd_apply");
+  return PTI_OK;
+}
+
+extern "C" int pti_pool2x2_sum(const void* x, void* y, int n, int h, int w, int c, pti_stream_t s) {
+  if (!x || !y || n <= 0 || h <= 0 || w <= 0 || c % 8) PTI_FAIL(PTI_EINVAL, "pool2x2_sum: bad args");
+  const long long total = (long long)n * h * w * (c / 8);
+  long long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(pool2x2_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, (const bf16*)x, (bf16*)y, n, h, w, c);
+  PTI_CHECK_LAUNCH("pool2x2_sum");
+  return PTI_OK;
+}

@@ -1,0 +1,336 @@
+// Weight / bias gradient of the implicit-GEMM convolutions (autograd of nn.Conv2d inside MONAI's
+// AEKLResBlock / AEKLDownsample / Upsample / SABlock linears; SURVEY.md §7 hard part 3) on
+// v_mfma_f32_32x32x16_bf16:
+//     dW[co][ci][tap] = sum_{n,p} dY[n,p,co] * A[n, p*S + tap - pad, ci],   A = prologue(x)
+// GEMM view: M = co, N = ci (per tap), K = pixels.  Both operands need K (pixels) as the
+// per-lane-contiguous index while NHWC memory has channels contiguous, so both MFMA fragments
+// come from gfx950's transposing LDS read ds_read_b64_tr_b16 on plain [pixel][channel] tiles.
+//
+// One workgroup (4 waves) owns a (<=64 co) x (<=64 ci) x (K*K taps) block of dW for one SPLIT of
+// the pixel tiles (split-K): each wave keeps 32co x 32ci x 9 taps = 144 accumulator VGPRs, the
+// GN+SiLU prologue is recomputed in the loader exactly as the forward conv does, partial blocks
+// go to a workspace slab with plain stores and pti_wgrad_reduce sums the slabs in a fixed order
+// (deterministic, no float atomics) into the fp32 OIHW gradient.
+#include "pti_common.h"
+
+namespace {
+
+constexpr int TH = 8, TW = 16;
+
+struct WgArgs {
+  const bf16* x;
+  const bf16* dy;
+  const float* in_stats;
+  const float* gamma;
+  const float* beta;
+  float* slab;  // [S][KK*Cout*Cin + Cout]
+  int N, H, W, Cin, Ho, Wo, Cout;
+  int mode, prologue, groups;
+  float eps, inv_cnt;
+  int tiles_x, tiles_y, ntiles, S;
+  int ci_tiles;
+  long long slab_stride;
+};
+
+template <int KS, int S_, int CO_T, int CI_T>
+struct WCfg {
+  static constexpr int HH = (TH - 1) * S_ + KS, HW = (TW - 1) * S_ + KS;
+  static constexpr int NP = HH * HW;
+  static constexpr int KK = KS * KS;
+  static constexpr int PA = CI_T * 2 + (CI_T == 64 ? 64 : 0);   // halo pixel pitch (bytes)
+  static constexpr int PD = CO_T * 2 + (CO_T == 64 ? 64 : 0);   // dY pixel pitch (bytes)
+  static constexpr int NCA = CI_T / 8, NCD = CO_T / 8;
+  static constexpr int WCO = CO_T / 32, WCI = CI_T / 32, WPX = 4 / (WCO * WCI);
+  static constexpr int A_BYTES = NP * PA, D_BYTES = TH * TW * PD;
+  static constexpr int HIT = (NP * NCA + 255) / 256, DIT = (TH * TW * NCD + 255) / 256;
+  static constexpr int RED_BYTES = (WPX > 1) ? 32 * 32 * 4 * (WPX - 1) * WCO * WCI : 0;  // per-tap cross-wave reduce
+  static constexpr int LDS_BYTES = (A_BYTES + D_BYTES) > RED_BYTES ? (A_BYTES + D_BYTES) : RED_BYTES;
+};
+
+template <int KS, int S_, int CO_T, int CI_T>
+__global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgArgs a) {
+  using C = WCfg<KS, S_, CO_T, CI_T>;
+  typedef short v4s __attribute__((ext_vector_type(4)));
+  __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS_BYTES];
+  unsigned char* lA = smem;
+  unsigned char* lD = smem + C::A_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int split = blockIdx.x;
+  const int cot = blockIdx.y / a.ci_tiles, cit = blockIdx.y % a.ci_tiles;
+  const int wco = wave / (C::WCI * C::WPX), wci = (wave / C::WPX) % C::WCI, wpx = wave % C::WPX;
+
+  const int pad_lo = (a.mode == PTI_CONV_S2PAD) ? 0 : (KS - 1) / 2;
+  const bool twox = (a.mode == PTI_CONV_UP2);
+  const int VH = twox ? 2 * a.H : a.H, VW = twox ? 2 * a.W : a.W;
+
+  // per-lane transposed-read bases (see header comment of tr reads in DESIGN.md):
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const int pk = 8 * (g >> 1) + q;                       // pixel within the 16-pixel k-block (first read)
+  const int chl = 16 * (g & 1) + 4 * pp;                 // channel within the wave's 32-channel block
+  const int dbase = pk * C::PD + (wco * 32 + chl) * 2;   // + row*TW*PD, second read + 4*PD
+  const int abase = (pk * S_) * C::PA + (wci * 32 + chl) * 2;  // + (row*S+kh)*HW*PA + kw*PA, second + 4*S*PA
+
+  f32x16 acc[C::KK];
+#pragma unroll
+  for (int t = 0; t < C::KK; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // loader geometry
+  const int alc = tid % C::NCA, alp = tid / C::NCA;
+  constexpr int APSTEP = 256 / C::NCA;
+  const int dlc = tid % C::NCD, dlp = tid / C::NCD;
+  constexpr int DPSTEP = 256 / C::NCD;
+  const int cpg = a.Cin / (a.groups > 0 ? a.groups : 1);
+  float bsum[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
+
+  u32x4 araw[C::HIT], draw[C::DIT];
+  bool aok[C::HIT];
+  int cur_n = -1;
+  float sc[8], sh[8];
+
+  auto issue_loads = [&](int tile) {
+    int t = tile;
+    const int tx_ = t % a.tiles_x; t /= a.tiles_x;
+    const int ty_ = t % a.tiles_y;
+    const int n = t / a.tiles_y;
+    const int oy0 = ty_ * TH, ox0 = tx_ * TW;
+    const int vy0 = oy0 * S_ - pad_lo, vx0 = ox0 * S_ - pad_lo;
+#pragma unroll
+    for (int it = 0; it < C::HIT; ++it) {
+      const int p = alp + it * APSTEP;
+      const int hy = p / C::HW, hx = p - hy * C::HW;
+      const int vy = vy0 + hy, vx = vx0 + hx;
+      const bool v = (p < C::NP) && vy >= 0 && vy < VH && vx >= 0 && vx < VW;
+      const int iy = twox ? (vy >> 1) : vy, ix = twox ? (vx >> 1) : vx;
+      aok[it] = v;
+      araw[it] = u32x4{0u, 0u, 0u, 0u};
+      if (v) araw[it] = *(const u32x4*)(a.x + ((size_t)(n * a.H + iy) * a.W + ix) * a.Cin + cit * CI_T + alc * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < C::DIT; ++it) {
+      const int p = dlp + it * DPSTEP;
+      const int ty = p / TW, tx = p % TW;
+      const int oy = oy0 + ty, ox = ox0 + tx;
+      draw[it] = u32x4{0u, 0u, 0u, 0u};
+      if (p < TH * TW && oy < a.Ho && ox < a.Wo)
+        draw[it] = *(const u32x4*)(a.dy + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.Cout + cot * CO_T + dlc * 8);
+    }
+    return n;
+  };
+
+  auto write_lds = [&](int n) {
+    if (a.prologue != PTI_PRO_NONE && n != cur_n) {
+      cur_n = n;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int ch = cit * CI_T + alc * 8 + j;
+        const int gg = ch / cpg;
+        const float sum = a.in_stats[(n * a.groups + gg) * 2], sq = a.in_stats[(n * a.groups + gg) * 2 + 1];
+        const float mean = sum * a.inv_cnt;
+        const float rstd = rsqrtf(fmaxf(sq * a.inv_cnt - mean * mean, 0.f) + a.eps);
+        sc[j] = rstd * a.gamma[ch];
+        sh[j] = a.beta[ch] - mean * sc[j];
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < C::HIT; ++it) {
+      const int p = alp + it * APSTEP;
+      if (p < C::NP) {
+        u32x4 r = araw[it];
+        if (a.prologue != PTI_PRO_NONE && aok[it]) {
+          float f[8];
+          unpack8(r, f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float v = f[j] * sc[j] + sh[j];
+            if (a.prologue == PTI_PRO_GN_SILU) v = silu_f(v);
+            f[j] = v;
+          }
+          r = pack8(f);
+        }
+        *(u32x4*)(lA + p * C::PA + alc * 16) = r;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < C::DIT; ++it) {
+      const int p = dlp + it * DPSTEP;
+      if (p < TH * TW) {
+        *(u32x4*)(lD + p * C::PD + dlc * 16) = draw[it];
+        if (cit == 0) {
+          float f[8];
+          unpack8(draw[it], f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bsum[j] += f[j];
+        }
+      }
+    }
+  };
+
+  int tile = split;
+  int n_next = -1;
+  if (tile < a.ntiles) n_next = issue_loads(tile);
+  for (; tile < a.ntiles; tile += a.S) {
+    write_lds(n_next);
+    __syncthreads();
+    const int nxt = tile + a.S;
+    if (nxt < a.ntiles) n_next = issue_loads(nxt);
+    // ---- MFMAs: this wave's tile rows ----
+#pragma unroll
+    for (int rr = 0; rr < TH / C::WPX; ++rr) {
+      const int row = wpx + rr * C::WPX;
+      const unsigned char* dptr = lD + dbase + row * TW * C::PD;
+      const v4s d0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(dptr));
+      const v4s d1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(dptr + 4 * C::PD));
+      bf16x8 dfrag;
+      {
+        typedef short v8s __attribute__((ext_vector_type(8)));
+        v8s t8 = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+        dfrag = __builtin_bit_cast(bf16x8, t8);
+      }
+#pragma unroll
+      for (int kh = 0; kh < KS; ++kh) {
+#pragma unroll
+        for (int kw = 0; kw < KS; ++kw) {
+          const unsigned char* aptr = lA + abase + ((row * S_ + kh) * C::HW + kw) * C::PA;
+          const v4s a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(aptr));
+          const v4s a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(aptr + 4 * S_ * C::PA));
+          typedef short v8s __attribute__((ext_vector_type(8)));
+          v8s t8 = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+          const bf16x8 afrag = __builtin_bit_cast(bf16x8, t8);
+          acc[kh * KS + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfrag, afrag, acc[kh * KS + kw], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: (cross-wave reduce when waves split pixels), write the slab [tap][co][ci] ----
+  float* slab = a.slab + (size_t)split * a.slab_stride;
+  const int ci = cit * CI_T + wci * 32 + (lane & 31);
+  const int hsel = lane >> 5;
+  float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int t = 0; t < C::KK; ++t) {
+    if constexpr (C::WPX > 1) {
+      // waves wpx>0 park their tap accumulators in LDS, wave wpx==0 of each (wco,wci) sums them
+      if (wpx > 0) {
+        float* dst = red + (((wco * C::WCI + wci) * (C::WPX - 1) + (wpx - 1)) * 16) * 64;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[r * 64 + lane] = acc[t][r];
+      }
+      __syncthreads();
+      if (wpx == 0) {
+#pragma unroll
+        for (int o = 0; o < C::WPX - 1; ++o) {
+          const float* src = red + (((wco * C::WCI + wci) * (C::WPX - 1) + o) * 16) * 64;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[t][r] += src[r * 64 + lane];
+        }
+      }
+      __syncthreads();
+    }
+    if (wpx == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = cot * CO_T + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
+        slab[((size_t)t * a.Cout + co) * a.Cin + ci] = acc[t][r];
+      }
+    }
+  }
+  // bias partial sums: reduce the threads that share dlc (stride NCD) through LDS
+  if (cit == 0) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[j * 256 + tid] = bsum[j];
+    __syncthreads();
+    if (tid < CO_T) {
+      const int lc = tid / 8, j = tid % 8;
+      float s = 0.f;
+      for (int k = lc; k < 256; k += C::NCD) s += red[j * 256 + k];
+      slab[(size_t)C::KK * a.Cout * a.Cin + cot * CO_T + tid] = s;
+    }
+  }
+}
+
+// dW[co][ci][tap] (=|+=) sum_s slab[s][tap][co][ci];  dbias[co] (=|+=) sum_s slab[s][KK*Cout*Cin + co]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, long long stride, int S, float* __restrict__ dw,
+                                    float* __restrict__ dbias, int Cout, int Cin, int KK, int accumulate) {
+  const long long total = (long long)KK * Cout * Cin;
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < total) {
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += slab[(size_t)k * stride + e];
+    const int ci = e % Cin;
+    const int co = (e / Cin) % Cout;
+    const int t = e / ((long long)Cin * Cout);
+    const size_t o = ((size_t)co * Cin + ci) * KK + t;
+    dw[o] = accumulate ? dw[o] + s : s;
+  } else if (dbias && e < total + Cout) {
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += slab[(size_t)k * stride + e];
+    const int co = (int)(e - total);
+    dbias[co] = accumulate ? dbias[co] + s : s;
+  }
+}
+
+template <int KS, int S_, int CO_T, int CI_T>
+void launch_w(const WgArgs& a, int grid_y, hipStream_t st) {
+  hipLaunchKernelGGL((wgrad_mfma_kernel<KS, S_, CO_T, CI_T>), dim3(a.S, grid_y), dim3(256), 0, st, a);
+}
+template <int KS, int S_>
+void launch_wt(const WgArgs& a, int co_t, int ci_t, int grid_y, hipStream_t st) {
+  if (co_t == 64 && ci_t == 64) launch_w<KS, S_, 64, 64>(a, grid_y, st);
+  else if (co_t == 64) launch_w<KS, S_, 64, 32>(a, grid_y, st);
+  else if (ci_t == 64) launch_w<KS, S_, 32, 64>(a, grid_y, st);
+  else launch_w<KS, S_, 32, 32>(a, grid_y, st);
+}
+
+}  // namespace
+
+extern "C" int64_t pti_conv_wgrad_workspace_bytes(int cout, int cin, int ksize, int splits) {
+  return (int64_t)splits * ((int64_t)ksize * ksize * cout * cin + cout) * 4;
+}
+
+extern "C" int pti_conv_wgrad_mfma(const void* x, const void* dy, const float* in_stats, const float* gamma,
+                                   const float* beta, float* dw, float* dbias, void* workspace,
+                                   int64_t workspace_bytes, int accumulate, const pti_conv_desc* d, pti_stream_t s) {
+  if (!x || !dy || !dw || !workspace || !d) PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma: null pointer");
+  if (d->cin % 32 || d->cout % 32) PTI_FAIL(PTI_EUNSUPPORTED, "conv_wgrad_mfma: cin=%d cout=%d", d->cin, d->cout);
+  if (d->ksize != 1 && d->ksize != 3) PTI_FAIL(PTI_EUNSUPPORTED, "conv_wgrad_mfma: ksize");
+  if (d->mode == PTI_CONV_ZINS || (d->ksize == 1 && d->mode != PTI_CONV_S1)) PTI_FAIL(PTI_EUNSUPPORTED, "conv_wgrad_mfma: mode %d", d->mode);
+  if (d->prologue != PTI_PRO_NONE && (!in_stats || !gamma || !beta || d->groups <= 0 || d->cin % d->groups))
+    PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma: prologue args");
+  WgArgs a;
+  a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.in_stats = in_stats; a.gamma = gamma; a.beta = beta;
+  a.slab = (float*)workspace;
+  a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Ho = d->ho; a.Wo = d->wo; a.Cout = d->cout;
+  a.mode = d->mode; a.prologue = d->prologue; a.groups = d->groups; a.eps = d->eps;
+  a.inv_cnt = d->prologue != PTI_PRO_NONE ? 1.0f / ((float)(d->cin / d->groups) * (float)d->h * (float)d->w) : 0.f;
+  a.tiles_x = cdiv(d->wo, TW); a.tiles_y = cdiv(d->ho, TH); a.ntiles = d->n * a.tiles_x * a.tiles_y;
+  const int co_t = d->cout % 64 == 0 ? 64 : 32, ci_t = d->cin % 64 == 0 ? 64 : 32;
+  a.ci_tiles = d->cin / ci_t;
+  const int tiles_cc = (d->cout / co_t) * a.ci_tiles;
+  const int kk = d->ksize * d->ksize;
+  a.slab_stride = (long long)kk * d->cout * d->cin + d->cout;
+  long long smax = workspace_bytes / (a.slab_stride * 4);
+  int S = 512 / tiles_cc;
+  if (S < 1) S = 1;
+  if (S > a.ntiles) S = a.ntiles;
+  if (S > smax) S = (int)smax;
+  if (S < 1) PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma: workspace too small (%lld bytes per split needed)", a.slab_stride * 4);
+  a.S = S;
+  hipStream_t st = (hipStream_t)s;
+  if (d->ksize == 1) launch_wt<1, 1>(a, co_t, ci_t, tiles_cc, st);
+  else if (d->mode == PTI_CONV_S2PAD) launch_wt<3, 2>(a, co_t, ci_t, tiles_cc, st);
+  else launch_wt<3, 1>(a, co_t, ci_t, tiles_cc, st);
+  PTI_CHECK_LAUNCH("conv_wgrad_mfma");
+  const long long total = a.slab_stride;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)workspace,
+                     a.slab_stride, S, dw, dbias, d->cout, d->cin, kk, accumulate);
+  PTI_CHECK_LAUNCH("conv_wgrad_reduce");
+  return PTI_OK;
+}

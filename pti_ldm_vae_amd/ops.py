@@ -159,3 +159,167 @@ def wgrad_direct(wide, narrow, dw, *, n, h, w, cw, cn, ksize, sgn, narrow_layout
                                      groups, eps, int(narrow.dtype == F32), ns, dw_strides[0], dw_strides[1],
                                      dw_strides[2], _stream()), "pti_wgrad_direct")
     return dw
+
+
+_WS = {}
+
+
+def wgrad_workspace(device, nbytes=48 << 20):
+    """One reusable split-K workspace per device (slabs of fp32 partial weight gradients)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    ws = _WS.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty(nbytes // 4, dtype=F32, device=device)
+        _WS[key] = ws
+    return ws
+
+
+def conv_wgrad_mfma(x, dy, dw, dbias, *, ksize=3, mode=PTI_CONV_S1, prologue=PTI_PRO_NONE, in_stats=None, gamma=None,
+                    beta=None, groups=0, eps=1e-6, accumulate=False, workspace=None):
+    _chk(x, BF16, "x", 4)
+    _chk(dy, BF16, "dy", 4)
+    _chk(dw, F32, "dw")
+    n, h, w, cin = x.shape
+    ho, wo = conv_out_hw(h, w, mode)
+    cout = dy.shape[3]
+    if tuple(dy.shape) != (n, ho, wo, cout):
+        raise ValueError(f"conv_wgrad_mfma: dy shape {tuple(dy.shape)} != {(n, ho, wo, cout)}")
+    if dw.numel() != cout * cin * ksize * ksize:
+        raise ValueError("conv_wgrad_mfma: dw size")
+    if dbias is not None:
+        _chk(dbias, F32, "dbias")
+        if dbias.numel() != cout:
+            raise ValueError("conv_wgrad_mfma: dbias size")
+    if prologue != PTI_PRO_NONE:
+        for t, nm, cnt in ((in_stats, "in_stats", n * groups * 2), (gamma, "gamma", cin), (beta, "beta", cin)):
+            _chk(t, F32, nm)
+            if t.numel() != cnt:
+                raise ValueError(f"conv_wgrad_mfma: {nm} size")
+    ws = workspace if workspace is not None else wgrad_workspace(x.device)
+    d = ConvDesc(n=n, h=h, w=w, cin=cin, ho=ho, wo=wo, cout=cout, ksize=ksize, mode=mode, prologue=prologue,
+                 groups=groups, eps=eps)
+    L.check(L.lib().pti_conv_wgrad_mfma(_ptr(x), _ptr(dy), _ptr(in_stats), _ptr(gamma), _ptr(beta), _ptr(dw),
+                                        _ptr(dbias), _ptr(ws), ws.numel() * 4, int(accumulate), C.byref(d),
+                                        _stream()), "pti_conv_wgrad_mfma")
+    return dw
+
+
+def gn_bwd(x, da, dx, stats, gamma, beta, sums, dgamma, dbeta, *, groups, eps=1e-6, silu=True, dres=None):
+    """dx <- backward of act(GroupNorm(x)); ``sums`` is a ZEROED fp32 [n,c,2] scratch."""
+    _chk(x, BF16, "x", 4)
+    _chk(da, BF16, "da", 4)
+    _chk(dx, BF16, "dx", 4)
+    n, h, w, c = x.shape
+    if da.shape != x.shape or dx.shape != x.shape or (dres is not None and dres.shape != x.shape):
+        raise ValueError("gn_bwd: shape mismatch")
+    if sums.numel() != n * c * 2 or stats.numel() != n * groups * 2:
+        raise ValueError("gn_bwd: scratch sizes")
+    L.check(L.lib().pti_gn_bwd(_ptr(x), _ptr(da), _ptr(dres), _ptr(dx), _ptr(stats), _ptr(gamma), _ptr(beta),
+                               _ptr(sums), _ptr(dgamma), _ptr(dbeta), n, h * w, c, groups, eps, int(silu), _stream()),
+            "pti_gn_bwd")
+    return dx
+
+
+def pool2x2_sum(x, y):
+    _chk(x, BF16, "x", 4)
+    _chk(y, BF16, "y", 4)
+    n, h2, w2, c = x.shape
+    if tuple(y.shape) != (n, h2 // 2, w2 // 2, c) or h2 % 2 or w2 % 2:
+        raise ValueError("pool2x2_sum: shapes")
+    L.check(L.lib().pti_pool2x2_sum(_ptr(x), _ptr(y), n, h2 // 2, w2 // 2, c, _stream()), "pti_pool2x2_sum")
+    return y
+
+
+def latent_head_fwd(h, eps, wm, bm, wl, bl, wp, bp, mu, sigma, logvar, zq):
+    b, hw, l = h.shape
+    for t, nm in ((h, "h"), (wm, "wm"), (bm, "bm"), (wl, "wl"), (bl, "bl"), (wp, "wp"), (bp, "bp"), (mu, "mu"),
+                  (sigma, "sigma"), (zq, "zq")):
+        _chk(t, F32, nm)
+    if mu.numel() != b * hw * l or sigma.numel() != b * hw * l or zq.numel() != b * hw * l:
+        raise ValueError("latent_head_fwd: output sizes")
+    if eps is not None and (eps.numel() != b * hw * l or eps.dtype != F32 or not eps.is_contiguous()):
+        raise ValueError("latent_head_fwd: eps must be contiguous fp32 of the latent shape")
+    L.check(L.lib().pti_latent_head_fwd(_ptr(h), _ptr(eps), _ptr(wm), _ptr(bm), _ptr(wl), _ptr(bl), _ptr(wp), _ptr(bp),
+                                        _ptr(mu), _ptr(sigma), _ptr(logvar), _ptr(zq), b, hw, l, _stream()),
+            "pti_latent_head_fwd")
+
+
+def post_quant(z_nchw, wp, bp, zq):
+    b, l = z_nchw.shape[0], z_nchw.shape[1]
+    hw = z_nchw.numel() // (b * l)
+    _chk(z_nchw, F32, "z")
+    L.check(L.lib().pti_post_quant(_ptr(z_nchw), _ptr(wp), _ptr(bp), _ptr(zq), b, hw, l, _stream()), "pti_post_quant")
+
+
+def latent_head_bwd(h, eps, wm, bm, wl, bl, wp, bp, dzq, dmu, dsigma, dh, gwm, gbm, gwl, gbl, gwp, gbp):
+    b, hw, l = h.shape
+    for t in (dzq, dmu, dsigma):
+        if t is not None and (t.dtype != F32 or not t.is_contiguous() or t.numel() != b * hw * l):
+            raise ValueError("latent_head_bwd: gradient inputs must be contiguous fp32 of the latent size")
+    L.check(L.lib().pti_latent_head_bwd(_ptr(h), _ptr(eps), _ptr(wm), _ptr(bm), _ptr(wl), _ptr(bl), _ptr(wp), _ptr(bp),
+                                        _ptr(dzq), _ptr(dmu), _ptr(dsigma), _ptr(dh), _ptr(gwm), _ptr(gbm), _ptr(gwl),
+                                        _ptr(gbl), _ptr(gwp), _ptr(gbp), b, hw, l, _stream()), "pti_latent_head_bwd")
+
+
+def vae_loss(recon, images, mu, third, out2, d_recon, d_mu, d_third, *, l2=False, third_mode=0, kl_weight=1e-3):
+    for t, nm in ((recon, "recon"), (images, "images"), (mu, "mu"), (third, "third"), (out2, "out2")):
+        _chk(t, F32, nm)
+    if recon.shape != images.shape or mu.shape != third.shape or out2.numel() < 2:
+        raise ValueError("vae_loss: shapes")
+    L.check(L.lib().pti_vae_loss(_ptr(recon), _ptr(images), recon.numel(), _ptr(mu), _ptr(third), mu.numel(),
+                                 recon.shape[0], _ptr(out2), _ptr(d_recon), _ptr(d_mu), _ptr(d_third), int(l2),
+                                 third_mode, kl_weight, _stream()), "pti_vae_loss")
+
+
+def adam_step(p, g, m, v, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, step=1, grad_scale=1.0):
+    for t, nm in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _chk(t, F32, nm)
+        if t.numel() != p.numel():
+            raise ValueError("adam_step: size mismatch")
+    L.check(L.lib().pti_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps, step,
+                                  grad_scale, _stream()), "pti_adam_step")
+
+
+def cast_nchw_f32_to_nhwc_bf16(x, y):
+    n, c = x.shape[0], x.shape[1]
+    _chk(x, F32, "x")
+    _chk(y, BF16, "y")
+    L.check(L.lib().pti_cast_nchw_f32_to_nhwc_bf16(_ptr(x), _ptr(y), n, c, x.numel() // (n * c), _stream()), "cast")
+    return y
+
+
+def cast_nhwc_bf16_to_nchw_f32(x, y):
+    n, c = y.shape[0], y.shape[1]
+    _chk(x, BF16, "x")
+    _chk(y, F32, "y")
+    L.check(L.lib().pti_cast_nhwc_bf16_to_nchw_f32(_ptr(x), _ptr(y), n, c, y.numel() // (n * c), _stream()), "cast")
+    return y
+
+
+def attention_fwd(qkv, o, lse2):
+    """qkv [B,L,3C] bf16 -> o [B,L,C] bf16, lse2 [B,L] fp32."""
+    _chk(qkv, BF16, "qkv", 3)
+    _chk(o, BF16, "o", 3)
+    _chk(lse2, F32, "lse2")
+    b, l, c3 = qkv.shape
+    c = c3 // 3
+    if tuple(o.shape) != (b, l, c) or lse2.numel() != b * l or c3 != 3 * c:
+        raise ValueError("attention_fwd: shapes")
+    L.check(L.lib().pti_attention_fwd(_ptr(qkv), _ptr(o), _ptr(lse2), b, l, c, _stream()), "pti_attention_fwd")
+    return o
+
+
+def attention_bwd(qkv, o, dout, lse2, delta, dqkv):
+    _chk(qkv, BF16, "qkv", 3)
+    _chk(o, BF16, "o", 3)
+    _chk(dout, BF16, "dout", 3)
+    _chk(dqkv, BF16, "dqkv", 3)
+    b, l, c3 = qkv.shape
+    c = c3 // 3
+    if o.shape != dout.shape or tuple(o.shape) != (b, l, c) or dqkv.shape != qkv.shape:
+        raise ValueError("attention_bwd: shapes")
+    if lse2.numel() != b * l or delta.numel() != b * l:
+        raise ValueError("attention_bwd: lse/delta sizes")
+    L.check(L.lib().pti_attention_bwd(_ptr(qkv), _ptr(o), _ptr(dout), _ptr(lse2), _ptr(delta), _ptr(dqkv), b, l, c,
+                                      _stream()), "pti_attention_bwd")
+    return dqkv

@@ -1,0 +1,57 @@
+"""CPU tests of the C-ABI boundary: the shared library loads, exports every symbol that
+include/pti_vae.h declares, and the ctypes binding table covers exactly that set.  No compute
+calls (no GPU here); argument validation paths that return before any launch ARE exercised.
+"""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "pti_vae.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(pti_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_symbols_are_bound_and_exported():
+    from pti_ldm_vae_amd import _lib
+    declared = _declared()
+    assert declared, "no declarations parsed"
+    assert sorted(_lib.SIGNATURES) == declared
+    handle = _lib.lib()
+    for name in declared:
+        assert hasattr(handle, name), f"{name} not exported by libpti_vae_hip.so"
+    assert handle.pti_abi_version() == 1
+
+
+def test_conv_desc_layout_matches_header():
+    from pti_ldm_vae_amd._lib import ConvDesc
+    # 15 int32/float fields + 2 int32 + 8 int64, 8-byte aligned
+    assert C.sizeof(ConvDesc) == 17 * 4 + 4 + 8 * 8
+    assert ConvDesc.in_stride.offset == 72 and ConvDesc.out_stride.offset == 104
+
+
+def test_validation_errors_before_launch():
+    from pti_ldm_vae_amd import _lib
+    h = _lib.lib()
+    assert h.pti_conv_packed_bytes(32, 48, 3, 0) == 0          # cin not a multiple of 32
+    assert h.pti_conv_packed_bytes(64, 32, 3, 0) == 2 * 64 * 32 * 9
+    d = _lib.ConvDesc(n=1, h=8, w=8, cin=32, ho=8, wo=8, cout=32, ksize=3)
+    rc = h.pti_conv2d_mfma(None, None, None, None, None, None, None, None, None, C.byref(d), None)
+    assert rc == -1 and b"null" in h.pti_last_error_string()
+    rc = h.pti_attention_fwd(C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), 1, 96, 128, None)
+    assert rc == -2 and b"multiple of 64" in h.pti_last_error_string()
+    with pytest.raises(_lib.PtiError):
+        _lib.check(rc, "attention")
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from pti_ldm_vae_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.PtiError, match="no CPU/PyTorch fallback"):
+        _lib.lib()
