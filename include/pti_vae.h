@@ -144,6 +144,9 @@ int pti_latent_head_fwd(const float* h, const float* eps, const float* wm, const
                         pti_stream_t s);
 int pti_post_quant(const float* z_nchw, const float* wp, const float* bp, float* zq_nhwc, int b,
                    int hw, int l, pti_stream_t s);
+/* backward of pti_post_quant: dz (NCHW, may be NULL), gwp/gbp += (atomics).                      */
+int pti_post_quant_bwd(const float* dzq_nhwc, const float* z_nchw, const float* wp, float* dz_nchw,
+                       float* gwp, float* gbp, int b, int hw, int l, pti_stream_t s);
 int pti_latent_head_bwd(const float* h, const float* eps, const float* wm, const float* bm,
                         const float* wl, const float* bl, const float* wp, const float* bp,
                         const float* dzq, const float* dmu, const float* dsigma, float* dh,

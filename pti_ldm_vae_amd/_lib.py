@@ -53,6 +53,7 @@ SIGNATURES = {
     "pti_attention_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "pti_latent_head_fwd": (_I, [_P] * 12 + [_I, _I, _I, _P]),
     "pti_post_quant": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "pti_post_quant_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "pti_latent_head_bwd": (_I, [_P] * 18 + [_I, _I, _I, _P]),
     "pti_vae_loss": (_I, [_P, _P, _I64, _P, _P, _I64, _I, _P, _P, _P, _P, _I, _I, _F, _P]),
     "pti_adam_step": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I, _F, _P]),

@@ -79,6 +79,36 @@ __global__ __launch_bounds__(256) void post_quant_kernel(const float* z, const f
   }
 }
 
+// backward of post_quant_kernel: dz[b][j][p] = sum_i wp[i][j] dzq[b][p][i]; gwp[i][j] += dzq_i z_j; gbp += dzq
+__global__ __launch_bounds__(256) void post_quant_bwd_kernel(const float* dzq, const float* z, const float* wp, float* dz,
+                                                             float* gwp, float* gbp, int B, int HW, int L) {
+  extern __shared__ float sm[];  // L*L + L
+  for (int i = threadIdx.x; i < L * L + L; i += 256) sm[i] = 0.f;
+  __syncthreads();
+  const long long total = (long long)B * HW;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int p = e % HW;
+    const int b = e / HW;
+    float g[MAXL], zz[MAXL];
+    for (int i = 0; i < L; ++i) {
+      g[i] = dzq[e * L + i];
+      zz[i] = z[((size_t)b * L + i) * HW + p];
+    }
+    for (int j = 0; j < L; ++j) {
+      float v = 0.f;
+      for (int i = 0; i < L; ++i) v += wp[i * L + j] * g[i];
+      if (dz) dz[((size_t)b * L + j) * HW + p] = v;
+    }
+    for (int i = 0; i < L; ++i) {
+      atomicAdd(&sm[L * L + i], g[i]);
+      for (int j = 0; j < L; ++j) atomicAdd(&sm[i * L + j], g[i] * zz[j]);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < L * L; i += 256) atomicAdd(&gwp[i], sm[i]);
+  for (int i = threadIdx.x; i < L; i += 256) atomicAdd(&gbp[i], sm[L * L + i]);
+}
+
 struct LatBwdArgs {
   const float* h; const float* eps;
   const float* wm; const float* bm; const float* wl; const float* bl; const float* wp; const float* bp;
@@ -272,6 +302,15 @@ extern "C" int pti_post_quant(const float* z_nchw, const float* wp, const float*
   hipLaunchKernelGGL(post_quant_kernel, dim3(nblocks((long long)b * hw)), dim3(256), 0, (hipStream_t)s, z_nchw, wp, bp,
                      zq_nhwc, b, hw, l);
   PTI_CHECK_LAUNCH("post_quant");
+  return PTI_OK;
+}
+
+extern "C" int pti_post_quant_bwd(const float* dzq_nhwc, const float* z_nchw, const float* wp, float* dz_nchw,
+                                  float* gwp, float* gbp, int b, int hw, int l, pti_stream_t s) {
+  if (!dzq_nhwc || !z_nchw || !wp || !gwp || !gbp || l <= 0 || l > MAXL) PTI_FAIL(PTI_EINVAL, "post_quant_bwd: bad args");
+  hipLaunchKernelGGL(post_quant_bwd_kernel, dim3(nblocks((long long)b * hw, 256)), dim3(256), (l * l + l) * sizeof(float),
+                     (hipStream_t)s, dzq_nhwc, z_nchw, wp, dz_nchw, gwp, gbp, b, hw, l);
+  PTI_CHECK_LAUNCH("post_quant_bwd");
   return PTI_OK;
 }
 

@@ -1,0 +1,537 @@
+"""HIP execution engine of the AutoencoderKL encoder / decoder (forward AND backward).
+
+It walks the same block list MONAI's ``Encoder`` / ``Decoder`` iterate over (SURVEY.md Appendix
+A.1/A.2) but never runs a PyTorch op on an activation: every step is one C-ABI launch
+(``pti_ldm_vae_amd/ops.py``) on NHWC bf16 tensors, with GroupNorm(+SiLU) folded into the loader of
+the consuming convolution, residual adds and the next GroupNorm's statistics folded into the
+producing convolution's epilogue, nearest-2x up-sampling / asymmetric-pad stride-2 folded into the
+conv's addressing, and the mid-block attention run flash-style.  PyTorch provides device memory
+(caching allocator), streams and autograd plumbing only.
+
+Two ``torch.autograd.Function`` s expose it: ``_EncodeFn`` (x -> z_mu, z_sigma) and ``_DecodeFn``
+(z -> reconstruction).  Their backward passes write weight gradients straight into the model's
+flat gradient arena and hand autograd views of it.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .models import autoencoderkl as M
+from .ops import (BF16, F32, PTI_CONV_S1, PTI_CONV_S2PAD, PTI_CONV_UP2, PTI_CONV_ZINS, PTI_PRO_GN, PTI_PRO_GN_SILU,
+                  PTI_PRO_NONE)
+
+
+class _Act:
+    """An NHWC bf16 activation plus (optionally) its GroupNorm {sum,sumsq} statistics."""
+
+    __slots__ = ("t", "stats")
+
+    def __init__(self, t, stats=None):
+        self.t, self.stats = t, stats
+
+
+def _empty(shape, like, dtype=BF16):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+# =================================================================================================
+# layers
+# =================================================================================================
+class _MfmaConv:
+    """One MFMA convolution's parameters, packed operands and gradient slots."""
+
+    def __init__(self, net, wname, bname, ksize, mode, fused_names=None):
+        self.net, self.ksize, self.mode = net, ksize, mode
+        self.wname, self.bname, self.fused = wname, bname, fused_names
+        if fused_names:  # q|k|v: three adjacent [C,C] weights seen as one [3C,C,1,1]
+            w0 = net._param_by_name[fused_names[0][0]]
+            self.cout, self.cin = 3 * w0.shape[0], w0.shape[1]
+        else:
+            w = net._param_by_name[wname]
+            self.cout, self.cin = w.shape[0], w.shape[1]
+        self.wp = self.wpt = None
+
+    def _w(self):
+        if self.fused:
+            o, n, _ = self.net._slots[self.fused[0][0]]
+            return self.net._arena[o:o + 3 * n].view(self.cout, self.cin, 1, 1)
+        return self.net._param_by_name[self.wname].data.view(self.cout, self.cin, self.ksize, self.ksize)
+
+    def bias(self):
+        if self.fused:
+            o, n, _ = self.net._slots[self.fused[0][1]]
+            return self.net._arena[o:o + 3 * n]
+        return self.net._param_by_name[self.bname].data
+
+    def grads(self):
+        if self.fused:
+            o, n, _ = self.net._slots[self.fused[0][0]]
+            ob, nb, _ = self.net._slots[self.fused[0][1]]
+            g = self.net.grad_arena
+            return g[o:o + 3 * n], g[ob:ob + 3 * nb]
+        return self.net.grad_view(self.wname).view(-1), self.net.grad_view(self.bname)
+
+    def repack(self):
+        w = self._w()
+        self.wp = ops.pack_conv_weight(w, self.ksize, self.mode, out=self.wp)
+        dmode = PTI_CONV_ZINS if self.mode == PTI_CONV_S2PAD else PTI_CONV_S1
+        self.wpt = ops.pack_conv_weight(w, self.ksize, dmode, flip=True, out=self.wpt)
+
+    # y = conv(prologue(x)) + b [+ residual]; optional fused stats of y
+    def fwd(self, x, *, pro=PTI_PRO_NONE, norm=None, residual=None, want_stats=False, eng=None):
+        n, h, w, _ = x.t.shape
+        ho, wo = ops.conv_out_hw(h, w, self.mode)
+        y = _empty((n, ho, wo, self.cout), x.t)
+        st = eng.new_stats(n) if want_stats else None
+        g, b = (norm.weight.data, norm.bias.data) if norm is not None else (None, None)
+        ops.conv_mfma(x.t, self.wp, self.bias(), y, cout=self.cout, ksize=self.ksize, mode=self.mode, prologue=pro,
+                      in_stats=x.stats if pro else None, gamma=g, beta=b, groups=eng.G, eps=eng.eps,
+                      residual=residual, out_stats=st, out_groups=eng.G)
+        return _Act(y, st)
+
+    # data gradient w.r.t. the (post-prologue) input
+    def dgrad(self, dy, *, residual=None):
+        n, ho, wo, _ = dy.shape
+        if self.mode == PTI_CONV_S2PAD:
+            out = _empty((n, 2 * ho, 2 * wo, self.cin), dy)
+            ops.conv_mfma(dy, self.wpt, None, out, cout=self.cin, ksize=3, mode=PTI_CONV_ZINS, residual=residual)
+            return out
+        out = _empty((n, ho, wo, self.cin), dy)
+        ops.conv_mfma(dy, self.wpt, None, out, cout=self.cin, ksize=self.ksize, mode=PTI_CONV_S1, residual=residual)
+        if self.mode == PTI_CONV_UP2:
+            pooled = _empty((n, ho // 2, wo // 2, self.cin), dy)
+            ops.pool2x2_sum(out, pooled)
+            return pooled
+        return out
+
+    def wgrad(self, x, dy, *, pro=PTI_PRO_NONE, norm=None, eng=None):
+        dw, db = self.grads()
+        g, b = (norm.weight.data, norm.bias.data) if norm is not None else (None, None)
+        ops.conv_wgrad_mfma(x.t, dy, dw, db, ksize=self.ksize, mode=self.mode, prologue=pro,
+                            in_stats=x.stats if pro else None, gamma=g, beta=b, groups=eng.G, eps=eng.eps,
+                            accumulate=True, workspace=eng.workspace)
+
+
+class _Norm:
+    def __init__(self, net, prefix):
+        self.net, self.prefix = net, prefix
+        self.weight = net._param_by_name[prefix + ".weight"]
+        self.bias = net._param_by_name[prefix + ".bias"]
+
+    def bwd(self, x, da, *, silu, dres, eng):
+        n, h, w, c = x.t.shape
+        dx = _empty(x.t.shape, x.t)
+        sums = torch.zeros(n, c, 2, dtype=F32, device=x.t.device)
+        ops.gn_bwd(x.t, da, dx, x.stats, self.weight.data, self.bias.data, sums,
+                   self.net.grad_view(self.prefix + ".weight"), self.net.grad_view(self.prefix + ".bias"),
+                   groups=eng.G, eps=eng.eps, silu=silu, dres=dres)
+        return dx
+
+
+class _ResBlock:
+    def __init__(self, net, p, blk):
+        self.norm1, self.norm2 = _Norm(net, p + ".norm1"), _Norm(net, p + ".norm2")
+        self.conv1 = _MfmaConv(net, p + ".conv1.conv.weight", p + ".conv1.conv.bias", 3, PTI_CONV_S1)
+        self.conv2 = _MfmaConv(net, p + ".conv2.conv.weight", p + ".conv2.conv.bias", 3, PTI_CONV_S1)
+        self.nin = None
+        if blk.in_channels != blk.out_channels:
+            self.nin = _MfmaConv(net, p + ".nin_shortcut.conv.weight", p + ".nin_shortcut.conv.bias", 1, PTI_CONV_S1)
+        self.convs = [c for c in (self.conv1, self.conv2, self.nin) if c is not None]
+        self.needs_in_stats = True
+
+    def fwd(self, x, eng, want_stats, save):
+        h1 = self.conv1.fwd(x, pro=PTI_PRO_GN_SILU, norm=self.norm1, want_stats=True, eng=eng)
+        sc = x.t if self.nin is None else self.nin.fwd(x, eng=eng).t
+        out = self.conv2.fwd(h1, pro=PTI_PRO_GN_SILU, norm=self.norm2, residual=sc, want_stats=want_stats, eng=eng)
+        if save is not None:
+            save.append((x, h1))
+        return out
+
+    def bwd(self, dout, saved, eng):
+        x, h1 = saved
+        da2 = self.conv2.dgrad(dout)
+        self.conv2.wgrad(h1, dout, pro=PTI_PRO_GN_SILU, norm=self.norm2, eng=eng)
+        dh1 = self.norm2.bwd(h1, da2, silu=True, dres=None, eng=eng)
+        del da2
+        da1 = self.conv1.dgrad(dh1)
+        self.conv1.wgrad(x, dh1, pro=PTI_PRO_GN_SILU, norm=self.norm1, eng=eng)
+        del dh1
+        if self.nin is None:
+            dres = dout
+        else:
+            dres = self.nin.dgrad(dout)
+            self.nin.wgrad(x, dout, eng=eng)
+        return self.norm1.bwd(x, da1, silu=True, dres=dres, eng=eng)
+
+
+class _Resample:
+    """AEKLDownsample (pad (0,1,0,1) + 3x3 stride 2) or Upsample (nearest 2x + 3x3)."""
+
+    def __init__(self, net, wprefix, mode):
+        self.conv = _MfmaConv(net, wprefix + ".weight", wprefix + ".bias", 3, mode)
+        self.convs = [self.conv]
+        self.needs_in_stats = False
+
+    def fwd(self, x, eng, want_stats, save):
+        out = self.conv.fwd(x, want_stats=want_stats, eng=eng)
+        if save is not None:
+            save.append(x)
+        return out
+
+    def bwd(self, dout, saved, eng):
+        x = saved
+        self.conv.wgrad(x, dout, eng=eng)
+        return self.conv.dgrad(dout)
+
+
+class _Attention:
+    def __init__(self, net, p):
+        self.norm = _Norm(net, p + ".norm")
+        a = p + ".attn."
+        self.qkv = _MfmaConv(net, None, None, 1, PTI_CONV_S1,
+                             fused_names=[(a + "to_q.weight", a + "to_q.bias")])
+        self.proj = _MfmaConv(net, a + "out_proj.weight", a + "out_proj.bias", 1, PTI_CONV_S1)
+        self.convs = [self.qkv, self.proj]
+        self.needs_in_stats = True
+
+    def fwd(self, x, eng, want_stats, save):
+        n, h, w, c = x.t.shape
+        qkv = self.qkv.fwd(x, pro=PTI_PRO_GN, norm=self.norm, eng=eng).t
+        o = _empty((n, h * w, c), x.t)
+        lse = _empty((n, h * w), x.t, F32)
+        ops.attention_fwd(qkv.view(n, h * w, 3 * c), o, lse)
+        out = self.proj.fwd(_Act(o.view(n, h, w, c)), residual=x.t, want_stats=want_stats, eng=eng)
+        if save is not None:
+            save.append((x, qkv, o, lse))
+        return out
+
+    def bwd(self, dout, saved, eng):
+        x, qkv, o, lse = saved
+        n, h, w, c = x.t.shape
+        do = self.proj.dgrad(dout)
+        self.proj.wgrad(_Act(o.view(n, h, w, c)), dout, eng=eng)
+        dqkv = _empty(qkv.shape, qkv)
+        delta = _empty((n, h * w), qkv, F32)
+        ops.attention_bwd(qkv.view(n, h * w, 3 * c), o, do.view(n, h * w, c), lse, delta, dqkv.view(n, h * w, 3 * c))
+        dxn = self.qkv.dgrad(dqkv)
+        self.qkv.wgrad(x, dqkv, pro=PTI_PRO_GN, norm=self.norm, eng=eng)
+        return self.norm.bwd(x, dxn, silu=False, dres=dout, eng=eng)
+
+
+class _DirectConv:
+    """Degenerate-channel 3x3 conv (conv_in / conv_out of Encoder and Decoder)."""
+
+    def __init__(self, net, prefix, norm_prefix=None):
+        self.net, self.prefix = net, prefix
+        self.w = net._param_by_name[prefix + ".weight"]
+        self.b = net._param_by_name[prefix + ".bias"]
+        self.cout, self.cin = self.w.shape[0], self.w.shape[1]
+        self.norm = _Norm(net, norm_prefix) if norm_prefix else None
+        self.few_cin = self.cin <= 16
+        self.w_tck = self.w_tck_t = None
+        self.convs = []
+        self.needs_in_stats = self.norm is not None
+
+    def repack(self):
+        w = self.w.data
+        self.w_tck = w.permute(2, 3, 1, 0).reshape(9, self.cin, self.cout).contiguous()
+        # data-gradient operand: w'[tap'][co][ci] = w[co][ci][8 - tap']
+        self.w_tck_t = w.flip(2, 3).permute(2, 3, 0, 1).reshape(9, self.cout, self.cin).contiguous()
+
+
+class _Plan:
+    """Shared forward/backward driver over a block list."""
+
+    def __init__(self, net, eng):
+        self.net, self.eng = net, eng
+        self.layers = []
+
+    def all_convs(self):
+        out = []
+        for l in self.layers:
+            out += l.convs
+        return out
+
+
+# =================================================================================================
+# engine
+# =================================================================================================
+class Engine:
+    def __init__(self, net: "M.AutoencoderKL"):
+        self.net = net
+        self.G, self.eps = net.norm_num_groups, float(net.norm_eps)
+        self.dev = net.param_arena.device
+        self.workspace = ops.wgrad_workspace(self.dev)
+        self.packed_version = -1
+        ops.L.lib()  # fail loudly now if the HIP extension is missing
+        for c in net.channels:
+            if c % 32:
+                raise ValueError(f"HIP path needs channel counts that are multiples of 32, got {net.channels}")
+            cpg = c // self.G
+            if cpg not in (2, 4, 8, 16, 32) or (c & (c - 1)):
+                raise ValueError(f"HIP GroupNorm path supports power-of-two channels with 2..32 channels per group; "
+                                 f"got channels={c}, groups={self.G}")
+        # ---- encoder plan ----
+        eb = net.encoder.blocks
+        self.enc_in = _DirectConv(net, "encoder.blocks.0.conv")
+        self.enc_layers = []
+        last = len(eb) - 1
+        for i in range(1, last - 1):
+            self.enc_layers.append(self._make_layer(eb[i], f"encoder.blocks.{i}"))
+        self.enc_out = _DirectConv(net, f"encoder.blocks.{last}.conv", norm_prefix=f"encoder.blocks.{last - 1}")
+        # ---- decoder plan ----
+        db = net.decoder.blocks
+        self.dec_in = _DirectConv(net, "decoder.blocks.0.conv")
+        self.dec_layers = []
+        last = len(db) - 1
+        for i in range(1, last - 1):
+            self.dec_layers.append(self._make_layer(db[i], f"decoder.blocks.{i}"))
+        self.dec_out = _DirectConv(net, f"decoder.blocks.{last}.conv", norm_prefix=f"decoder.blocks.{last - 1}")
+        self.mfma_convs = [c for l in self.enc_layers + self.dec_layers for c in l.convs]
+        self.direct_convs = [self.enc_in, self.enc_out, self.dec_in, self.dec_out]
+        self.Lc = net.latent_channels
+
+    def _make_layer(self, blk, prefix):
+        if isinstance(blk, M.AEKLResBlock):
+            return _ResBlock(self.net, prefix, blk)
+        if isinstance(blk, M.AEKLDownsample):
+            return _Resample(self.net, prefix + ".conv.conv", PTI_CONV_S2PAD)
+        if isinstance(blk, M.Upsample):
+            return _Resample(self.net, prefix + ".postconv.conv", PTI_CONV_UP2)
+        if isinstance(blk, M.SpatialAttentionBlock):
+            return _Attention(self.net, prefix)
+        raise TypeError(f"unsupported block {type(blk)} at {prefix}")
+
+    # ---- helpers -------------------------------------------------------------------------------
+    def new_stats(self, n):
+        return torch.zeros(n, self.G, 2, dtype=F32, device=self.dev)
+
+    def refresh_weights(self):
+        """Re-derive the bf16 MFMA-packed / transposed operands when the fp32 masters changed."""
+        v = self.net.param_arena._version
+        if v == self.packed_version:
+            return
+        for c in self.mfma_convs:
+            c.repack()
+        for c in self.direct_convs:
+            c.repack()
+        self.packed_version = self.net.param_arena._version
+
+    def _qp(self, name):
+        L = self.Lc
+        w = self.net._param_by_name[name + ".conv.weight"].data.view(L, L)
+        b = self.net._param_by_name[name + ".conv.bias"].data
+        return w, b
+
+    def _check_input(self, x, channels, what):
+        if not x.is_cuda:
+            raise RuntimeError(f"{what}: expected a cuda (HIP) tensor; the VAE hot path has no CPU fallback")
+        if x.dim() != 4 or x.shape[1] != channels:
+            raise ValueError(f"{what}: expected [B,{channels},H,W], got {tuple(x.shape)}")
+        if x.dtype != F32:
+            x = x.float()
+        return x.contiguous()
+
+    # ---- block-list walkers ---------------------------------------------------------------------
+    def _walk_fwd(self, layers, act, tail_needs_stats, save):
+        for i, l in enumerate(layers):
+            nxt_needs = layers[i + 1].needs_in_stats if i + 1 < len(layers) else tail_needs_stats
+            act = l.fwd(act, self, nxt_needs, save)
+        return act
+
+    def _walk_bwd(self, layers, dout, saved):
+        for l, s in zip(reversed(layers), reversed(saved)):
+            dout = l.bwd(dout, s, self)
+        return dout
+
+    # ---- encoder --------------------------------------------------------------------------------
+    def encode_forward(self, x, save):
+        self.refresh_weights()
+        x = self._check_input(x, self.net.in_channels, "encode")
+        n, cin, h, w = x.shape
+        down = 2 ** (len(self.net.channels) - 1)
+        if h % down or w % down:
+            raise ValueError(f"encode: H,W must be multiples of {down}, got {h}x{w}")
+        c0 = self.net.channels[0]
+        t0 = _empty((n, h, w, c0), x)
+        ops.conv_direct(x, self.enc_in.w_tck, self.enc_in.b.data, t0, n=n, h=h, w=w, cin=cin, cout=c0, x_layout="nchw")
+        a0 = _Act(t0, ops.gn_stats(t0, self.G))
+        saved = [] if save else None
+        act = self._walk_fwd(self.enc_layers, a0, True, saved)
+        hl, wl, L = act.t.shape[1], act.t.shape[2], self.Lc
+        hlat = _empty((n, hl * wl, L), x, F32)
+        nm = self.enc_out.norm
+        ops.conv_direct(act.t, self.enc_out.w_tck, self.enc_out.b.data, hlat.view(n, hl, wl, L), n=n, h=hl, w=wl, cin=act.t.shape[3], cout=L,
+                        prologue=PTI_PRO_GN, in_stats=act.stats, gamma=nm.weight.data, beta=nm.bias.data, groups=self.G,
+                        eps=self.eps)
+        mu = _empty((n, L, hl, wl), x, F32)
+        sigma = _empty((n, L, hl, wl), x, F32)
+        zq_unused = _empty((n, hl * wl, L), x, F32)
+        wm, bm = self._qp("quant_conv_mu")
+        wl_, bl = self._qp("quant_conv_log_sigma")
+        wp, bp = self._qp("post_quant_conv")
+        ops.latent_head_fwd(hlat, None, wm, bm, wl_, bl, wp, bp, mu, sigma, None, zq_unused)
+        ctx = (x, a0, saved, act, hlat) if save else None
+        return mu, sigma, ctx
+
+    def encode_backward(self, ctx, dmu, dsigma, want_dx=False):
+        x, a0, saved, act, hlat = ctx
+        net = self.net
+        n, L = hlat.shape[0], self.Lc
+        hl, wl = act.t.shape[1], act.t.shape[2]
+        wm, bm = self._qp("quant_conv_mu")
+        wl_, bl = self._qp("quant_conv_log_sigma")
+        wp, bp = self._qp("post_quant_conv")
+        dh = torch.empty_like(hlat)
+        gv = net.grad_view
+        scratch = torch.zeros(L * L + L, dtype=F32, device=self.dev)   # post_quant grads are not produced here
+        ops.latent_head_bwd(hlat, None, wm, bm, wl_, bl, wp, bp, None,
+                            None if dmu is None else dmu.contiguous().float(),
+                            None if dsigma is None else dsigma.contiguous().float(), dh,
+                            gv("quant_conv_mu.conv.weight"), gv("quant_conv_mu.conv.bias"),
+                            gv("quant_conv_log_sigma.conv.weight"), gv("quant_conv_log_sigma.conv.bias"),
+                            scratch[:L * L], scratch[L * L:])
+        # encoder conv_out (norm + 3x3, C -> L): weight grads, then data grad through the norm
+        eo, nm = self.enc_out, self.enc_out.norm
+        C = act.t.shape[3]
+        ops.wgrad_direct(act.t, dh.view(n, hl, wl, L), gv(eo.prefix + ".weight"), n=n, h=hl, w=wl, cw=C, cn=L, ksize=3,
+                         sgn=1, narrow_layout="nhwc", dw_strides=(1, 9, C * 9), dbias_narrow=gv(eo.prefix + ".bias"),
+                         prologue=PTI_PRO_GN, in_stats=act.stats, gamma=nm.weight.data, beta=nm.bias.data, groups=self.G,
+                         eps=self.eps)
+        da = _empty(act.t.shape, x)
+        ops.conv_direct(dh.view(n, hl, wl, L), eo.w_tck_t, None, da, n=n, h=hl, w=wl, cin=L, cout=C)
+        dout = nm.bwd(act, da, silu=False, dres=None, eng=self)
+        dout = self._walk_bwd(self.enc_layers, dout, saved)
+        # encoder conv_in (cin -> C0): weight grads; data grad only on request
+        ei = self.enc_in
+        _, cin, h, w = x.shape
+        c0 = dout.shape[3]
+        ops.wgrad_direct(dout, x, gv(ei.prefix + ".weight"), n=n, h=h, w=w, cw=c0, cn=cin, ksize=3, sgn=-1,
+                         narrow_layout="nchw", dw_strides=(1, cin * 9, 9), dbias_wide=gv(ei.prefix + ".bias"))
+        if not want_dx:
+            return None
+        dx = torch.empty_like(x)
+        ops.conv_direct(dout, ei.w_tck_t, None, dx, n=n, h=h, w=w, cin=c0, cout=cin, y_layout="nchw")
+        return dx
+
+    # ---- decoder --------------------------------------------------------------------------------
+    def decode_forward(self, z, save):
+        self.refresh_weights()
+        z = self._check_input(z, self.Lc, "decode")
+        n, L, hl, wl = z.shape
+        wp, bp = self._qp("post_quant_conv")
+        zq = _empty((n, hl * wl, L), z, F32)
+        ops.post_quant(z, wp, bp, zq)
+        di = self.dec_in
+        t0 = _empty((n, hl, wl, di.cout), z)
+        ops.conv_direct(zq.view(n, hl, wl, L), di.w_tck, di.b.data, t0, n=n, h=hl, w=wl, cin=L, cout=di.cout)
+        a0 = _Act(t0, ops.gn_stats(t0, self.G))
+        saved = [] if save else None
+        act = self._walk_fwd(self.dec_layers, a0, True, saved)
+        h, w, C = act.t.shape[1], act.t.shape[2], act.t.shape[3]
+        do, nm = self.dec_out, self.dec_out.norm
+        recon = _empty((n, do.cout, h, w), z, F32)
+        ops.conv_direct(act.t, do.w_tck, do.b.data, recon, n=n, h=h, w=w, cin=C, cout=do.cout, y_layout="nchw",
+                        prologue=PTI_PRO_GN, in_stats=act.stats, gamma=nm.weight.data, beta=nm.bias.data, groups=self.G,
+                        eps=self.eps)
+        ctx = (z, zq, a0, saved, act) if save else None
+        return recon, ctx
+
+    def decode_backward(self, ctx, drecon, want_dz=True):
+        z, zq, a0, saved, act = ctx
+        net, gv = self.net, self.net.grad_view
+        n, L, hl, wl = z.shape
+        drecon = drecon.contiguous().float()
+        do, nm = self.dec_out, self.dec_out.norm
+        h, w, C = act.t.shape[1], act.t.shape[2], act.t.shape[3]
+        co = do.cout
+        ops.wgrad_direct(act.t, drecon, gv(do.prefix + ".weight"), n=n, h=h, w=w, cw=C, cn=co, ksize=3, sgn=1,
+                         narrow_layout="nchw", dw_strides=(1, 9, C * 9), dbias_narrow=gv(do.prefix + ".bias"),
+                         prologue=PTI_PRO_GN, in_stats=act.stats, gamma=nm.weight.data, beta=nm.bias.data, groups=self.G,
+                         eps=self.eps)
+        da = _empty(act.t.shape, z)
+        ops.conv_direct(drecon, do.w_tck_t, None, da, n=n, h=h, w=w, cin=co, cout=C, x_layout="nchw")
+        dout = nm.bwd(act, da, silu=False, dres=None, eng=self)
+        dout = self._walk_bwd(self.dec_layers, dout, saved)
+        di = self.dec_in
+        ops.wgrad_direct(dout, zq.view(n, hl, wl, L), gv(di.prefix + ".weight"), n=n, h=hl, w=wl, cw=di.cout, cn=L,
+                         ksize=3, sgn=-1, narrow_layout="nhwc", dw_strides=(1, L * 9, 9),
+                         dbias_wide=gv(di.prefix + ".bias"))
+        dzq = _empty((n, hl * wl, L), z, F32)
+        ops.conv_direct(dout, di.w_tck_t, None, dzq.view(n, hl, wl, L), n=n, h=hl, w=wl, cin=di.cout, cout=L)
+        wp, _ = self._qp("post_quant_conv")
+        dz = torch.empty_like(z) if want_dz else None
+        ops.post_quant_bwd(dzq, z, wp, dz, gv("post_quant_conv.conv.weight"), gv("post_quant_conv.conv.bias"))
+        return dz
+
+    # ---- autograd entry points --------------------------------------------------------------------
+    def _region_params(self, which):
+        pre = ("encoder.", "quant_conv_") if which == 0 else ("post_quant_conv.", "decoder.")
+        return [(n, p) for n, p in self.net._param_by_name.items() if n.startswith(pre)]
+
+    def encode(self, x):
+        params = self._region_params(0)
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for _, p in params)):
+            return _EncodeFn.apply(self, x, *[p for _, p in params])
+        mu, sigma, _ = self.encode_forward(x, save=False)
+        return mu, sigma
+
+    def decode(self, z):
+        params = self._region_params(1)
+        if torch.is_grad_enabled() and (z.requires_grad or any(p.requires_grad for _, p in params)):
+            return _DecodeFn.apply(self, z, *[p for _, p in params])
+        recon, _ = self.decode_forward(z, save=False)
+        return recon
+
+    def _prepare_grads(self, which):
+        """Zero this region of the gradient arena unless the parameters' .grad already alias it (then
+        the kernels keep accumulating in place).  Returns True when autograd must be handed views."""
+        net = self.net
+        params = self._region_params(which)
+        aliased = all(p.grad is not None and p.grad.data_ptr() == net.grad_view(n).data_ptr() for n, p in params
+                      if p.requires_grad)
+        if aliased and any(p.requires_grad for _, p in params):
+            return False
+        s, e = net.arena_regions()[which]
+        net.grad_arena[s:e].zero_()
+        return True
+
+    def _grad_outputs(self, which, hand_views, needs):
+        out = []
+        for (n, p), need in zip(self._region_params(which), needs):
+            out.append(self.net.grad_view(n) if (hand_views and need) else None)
+        return out
+
+
+class _EncodeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eng, x, *params):
+        mu, sigma, c = eng.encode_forward(x, save=True)
+        ctx.eng, ctx.c = eng, c
+        return mu, sigma
+
+    @staticmethod
+    def backward(ctx, dmu, dsigma):
+        eng = ctx.eng
+        hand = eng._prepare_grads(0)
+        want_dx = ctx.needs_input_grad[1]
+        dx = eng.encode_backward(ctx.c, dmu, dsigma, want_dx=want_dx)
+        ctx.c = None
+        return (None, dx, *eng._grad_outputs(0, hand, ctx.needs_input_grad[2:]))
+
+
+class _DecodeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eng, z, *params):
+        recon, c = eng.decode_forward(z, save=True)
+        ctx.eng, ctx.c = eng, c
+        return recon
+
+    @staticmethod
+    def backward(ctx, drecon):
+        eng = ctx.eng
+        hand = eng._prepare_grads(1)
+        dz = eng.decode_backward(ctx.c, drecon, want_dz=ctx.needs_input_grad[1])
+        ctx.c = None
+        return (None, dz, *eng._grad_outputs(1, hand, ctx.needs_input_grad[2:]))

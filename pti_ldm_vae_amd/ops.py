@@ -251,6 +251,17 @@ def post_quant(z_nchw, wp, bp, zq):
     L.check(L.lib().pti_post_quant(_ptr(z_nchw), _ptr(wp), _ptr(bp), _ptr(zq), b, hw, l, _stream()), "pti_post_quant")
 
 
+def post_quant_bwd(dzq, z_nchw, wp, dz, gwp, gbp):
+    b, l = z_nchw.shape[0], z_nchw.shape[1]
+    hw = z_nchw.numel() // (b * l)
+    _chk(dzq, F32, "dzq")
+    _chk(z_nchw, F32, "z")
+    if dzq.numel() != z_nchw.numel() or (dz is not None and dz.numel() != z_nchw.numel()):
+        raise ValueError("post_quant_bwd: sizes")
+    L.check(L.lib().pti_post_quant_bwd(_ptr(dzq), _ptr(z_nchw), _ptr(wp), _ptr(dz), _ptr(gwp), _ptr(gbp), b, hw, l,
+                                       _stream()), "pti_post_quant_bwd")
+
+
 def latent_head_bwd(h, eps, wm, bm, wl, bl, wp, bp, dzq, dmu, dsigma, dh, gwm, gbm, gwl, gbl, gwp, gbp):
     b, hw, l = h.shape
     for t in (dzq, dmu, dsigma):
