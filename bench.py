@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py — VAE training throughput of the hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one optimiser step of the reference's train loop body (vae_scripts/train_vae.py:380-445:
+zero_grad, forward encode+sample+decode, L1 recon + 1e-3*KL, backward, gradient all-reduce, Adam) on one
+batch of synthetic 256x256x1 images per GPU (config/vae_dente_no_adv.json: channels [32,64,128,128],
+16 groups, latent 4; batch 32 per GPU, weak scaling).  Perceptual (LPIPS) and adversarial terms are
+omitted: unavailable offline / inactive before epoch 6 — stated in ``config``.
+Inputs are resident in HBM before the timed region.  For N>1 launch with
+``python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...``.
+
+Prints ONE JSON line (rank 0): metric/value/unit/..., plus
+  "roofline":     dominant kernel (by time) among the MFMA conv kernels, timed with events on the launch
+                  stream during extra instrumented steps right after the timed region (so the headline
+                  number is not perturbed); achieved = algorithmic FLOP per launch / avg launch duration.
+  "cpu_baseline": the CPU fp32 oracle's training step (oracle/, kind "port") on the host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+TRAIN_GFLOP_PER_IMG_A = 148.11   # BASELINE.md §3 (config A, 256x256, 1 channel; fwd 49.37 x 3)
+
+
+def synthetic_batch(batch, channels, size, device, seed):
+    """z-scored elliptical foreground (~40 % of pixels), exact-zero background."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    x = torch.randn(batch, channels, size, size, generator=g, device=device)
+    lin = torch.linspace(-1, 1, size, device=device)
+    yy, xx = torch.meshgrid(lin, lin, indexing="ij")
+    return (x * ((xx / 0.80) ** 2 + (yy / 0.64) ** 2 <= 1.0).float()).contiguous()
+
+
+def cpu_baseline(cfg_def, size, batch, steps):
+    """Oracle (CPU fp32 restatement) training step, timed on this box's host cores."""
+    from oracle.autoencoderkl import build_oracle, synthetic_images
+    from oracle.losses import train_step_losses
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))      # the GPU box grants a 16-core share per GPU
+    torch.set_num_threads(cores)
+    model = build_oracle(cfg_def, seed=42)
+    opt = torch.optim.Adam(model.parameters(), lr=2.5e-5)
+    x = synthetic_images(batch, cfg_def["in_channels"], size, seed=42)
+    lat = size // (2 ** (len(cfg_def["channels"]) - 1))
+    times = []
+    for i in range(steps + 1):
+        eps = torch.randn(batch, cfg_def["latent_channels"], lat, lat)
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        loss, *_ = train_step_losses(model, x, eps)
+        loss.backward()
+        opt.step()
+        if i > 0:
+            times.append(time.perf_counter() - t0)
+    dt = sum(times) / len(times)
+    return {"value": round(batch / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32 train step (fwd+L1+KL+bwd+Adam), config A {size}x{size}, batch {batch}, "
+                      f"1 warm-up + {steps} timed steps, torch threads={cores}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--config", default=os.path.join(ROOT, "config", "vae_dente_no_adv.json"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from pti_ldm_vae_amd.models import VAEModel
+    from pti_ldm_vae_amd.trainer import VAETrainer
+    from pti_ldm_vae_amd.utils import read_config
+    from pti_ldm_vae_amd import ops
+
+    world = args.gpus
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        if int(os.environ.get("WORLD_SIZE", "1")) != world:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N (WORLD_SIZE must equal --gpus)")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", init_method="env://")
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+
+    cfg = read_config(args.config)
+    cfg_def = cfg["autoencoder_def"]
+    tr = cfg["autoencoder_train"]
+    torch.manual_seed(42)                       # set_determinism(args.seed), train_vae.py:808
+    model = VAEModel.from_config(cfg_def).to(dev)
+    trainer = VAETrainer(model, lr=tr["lr"], world_size=world, recon_loss=tr["recon_loss"], kl_weight=tr["kl_weight"],
+                         rank_eps_offset=rank)
+    images = synthetic_batch(args.batch, cfg_def["in_channels"], args.size, dev, seed=42 + rank)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    log(f"model built, {sum(p.numel() for p in model.parameters())} params; warm-up {args.warmup} steps")
+    for i in range(args.warmup):
+        trainer.step(images)
+        if i == 0:
+            torch.cuda.synchronize()
+            log("first step done")
+    sync_all()
+    log(f"timing {args.steps} steps")
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = trainer.step(images)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = float(out["loss"].item())
+    log(f"timed region {dt:.3f}s, loss {loss:.5f}; instrumented steps")
+
+    # ---- instrumented steps: per-launch event timing of the MFMA conv kernels (rank 0) ----
+    roofline = None
+    if rank == 0:
+        ops.KERNEL_PROFILE = []
+        for _ in range(2):
+            trainer.step(images)
+        torch.cuda.synchronize()
+        rec, ops.KERNEL_PROFILE = ops.KERNEL_PROFILE, None
+        agg = {}
+        for name, flops, nbytes, e0, e1 in rec:
+            a = agg.setdefault(name, [0.0, 0.0, 0.0, 0])
+            a[0] += e0.elapsed_time(e1) * 1e-3
+            a[1] += flops
+            a[2] += nbytes
+            a[3] += 1
+        if agg:
+            name, (tsec, flops, nbytes, cnt) = max(agg.items(), key=lambda kv: kv[1][0])
+            ach = flops / tsec / 1e12
+            roofline = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                        "launches_per_step": cnt // 2, "avg_launch_us": round(tsec / cnt * 1e6, 2),
+                        "algorithmic_gflop_per_launch": round(flops / cnt / 1e9, 3),
+                        "algorithmic_hbm_gbs": round(nbytes / tsec / 1e9, 1),
+                        "all_conv_kernels": {k: {"ms_per_step": round(v[0] / 2 * 1e3, 3),
+                                                 "tflops": round(v[1] / v[0] / 1e12, 1), "launches": v[3] // 2}
+                                             for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        imgs = args.batch * world * args.steps
+        value = imgs / dt
+        per_gpu = value / world
+        line = {
+            "metric": "vae_train_images_per_sec_256x256_bf16", "value": round(value, 2), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"config/vae_dente_no_adv.json {args.size}x{args.size}x{cfg_def['in_channels']} "
+                                   f"batch {args.batch}/GPU: fwd + L1 + 1e-3*KL + bwd + all-reduce + Adam "
+                                   "(perceptual/adversarial terms omitted: unavailable offline / inactive before epoch 6)",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss, 5)},
+            "model_tflops_per_gpu": round(per_gpu * TRAIN_GFLOP_PER_IMG_A / 1e3, 1),
+            "frac_of_mfma_peak_end_to_end": round(per_gpu * TRAIN_GFLOP_PER_IMG_A / 1e3 / PEAK_BF16_TFLOPS, 4),
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            log("cpu baseline (oracle) ...")
+            line["cpu_baseline"] = cpu_baseline(cfg_def, args.size, 2, args.cpu_steps)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

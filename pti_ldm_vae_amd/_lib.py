@@ -77,6 +77,9 @@ def lib() -> C.CDLL:
                 f"{LIB_PATH} is missing: the HIP extension was not built. Run "
                 "`python -c 'import __graft_entry__ as g; g.build()'` (or pti_ldm_vae_amd/csrc/build.sh). "
                 "There is no CPU/PyTorch fallback for the VAE hot path.")
+        # torch must load ITS HIP runtime first: the extension then binds to the same libamdhip64 instead of
+        # pulling a second copy from /opt/rocm (two runtimes in one process => "no ROCm-capable device").
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported

@@ -139,6 +139,7 @@ class _ResBlock:
             self.nin = _MfmaConv(net, p + ".nin_shortcut.conv.weight", p + ".nin_shortcut.conv.bias", 1, PTI_CONV_S1)
         self.convs = [c for c in (self.conv1, self.conv2, self.nin) if c is not None]
         self.needs_in_stats = True
+        self.prefix = p + "."
 
     def fwd(self, x, eng, want_stats, save):
         h1 = self.conv1.fwd(x, pro=PTI_PRO_GN_SILU, norm=self.norm1, want_stats=True, eng=eng)
@@ -168,10 +169,11 @@ class _ResBlock:
 class _Resample:
     """AEKLDownsample (pad (0,1,0,1) + 3x3 stride 2) or Upsample (nearest 2x + 3x3)."""
 
-    def __init__(self, net, wprefix, mode):
+    def __init__(self, net, wprefix, mode, prefix):
         self.conv = _MfmaConv(net, wprefix + ".weight", wprefix + ".bias", 3, mode)
         self.convs = [self.conv]
         self.needs_in_stats = False
+        self.prefix = prefix
 
     def fwd(self, x, eng, want_stats, save):
         out = self.conv.fwd(x, want_stats=want_stats, eng=eng)
@@ -194,6 +196,7 @@ class _Attention:
         self.proj = _MfmaConv(net, a + "out_proj.weight", a + "out_proj.bias", 1, PTI_CONV_S1)
         self.convs = [self.qkv, self.proj]
         self.needs_in_stats = True
+        self.prefix = p + "."
 
     def fwd(self, x, eng, want_stats, save):
         n, h, w, c = x.t.shape
@@ -264,6 +267,8 @@ class Engine:
         self.dev = net.param_arena.device
         self.workspace = ops.wgrad_workspace(self.dev)
         self.packed_version = -1
+        self.grad_ready_cb = None
+        self._range_cache = {}
         ops.L.lib()  # fail loudly now if the HIP extension is missing
         for c in net.channels:
             if c % 32:
@@ -296,9 +301,9 @@ class Engine:
         if isinstance(blk, M.AEKLResBlock):
             return _ResBlock(self.net, prefix, blk)
         if isinstance(blk, M.AEKLDownsample):
-            return _Resample(self.net, prefix + ".conv.conv", PTI_CONV_S2PAD)
+            return _Resample(self.net, prefix + ".conv.conv", PTI_CONV_S2PAD, prefix + ".")
         if isinstance(blk, M.Upsample):
-            return _Resample(self.net, prefix + ".postconv.conv", PTI_CONV_UP2)
+            return _Resample(self.net, prefix + ".postconv.conv", PTI_CONV_UP2, prefix + ".")
         if isinstance(blk, M.SpatialAttentionBlock):
             return _Attention(self.net, prefix)
         raise TypeError(f"unsupported block {type(blk)} at {prefix}")
@@ -343,7 +348,24 @@ class Engine:
     def _walk_bwd(self, layers, dout, saved):
         for l, s in zip(reversed(layers), reversed(saved)):
             dout = l.bwd(dout, s, self)
+            self._ready(l.prefix)
         return dout
+
+    def _ready(self, *prefixes):
+        """Tell the data-parallel exchange that the gradients of these blocks are final."""
+        cb = self.grad_ready_cb
+        if cb is None:
+            return
+        rng = self._range_cache.get(prefixes)
+        if rng is None:
+            lo, hi = None, None
+            for name, (o, n, _) in self.net._slots.items():
+                if name.startswith(prefixes):
+                    lo = o if lo is None else min(lo, o)
+                    hi = o + (n + 3) // 4 * 4 if hi is None else max(hi, o + (n + 3) // 4 * 4)
+            rng = self._range_cache[prefixes] = (lo, hi)
+        if rng[0] is not None:
+            cb(*rng)
 
     # ---- encoder --------------------------------------------------------------------------------
     def encode_forward(self, x, save):
@@ -392,6 +414,7 @@ class Engine:
                             gv("quant_conv_mu.conv.weight"), gv("quant_conv_mu.conv.bias"),
                             gv("quant_conv_log_sigma.conv.weight"), gv("quant_conv_log_sigma.conv.bias"),
                             scratch[:L * L], scratch[L * L:])
+        self._ready("quant_conv_mu.", "quant_conv_log_sigma.")
         # encoder conv_out (norm + 3x3, C -> L): weight grads, then data grad through the norm
         eo, nm = self.enc_out, self.enc_out.norm
         C = act.t.shape[3]
@@ -402,6 +425,7 @@ class Engine:
         da = _empty(act.t.shape, x)
         ops.conv_direct(dh.view(n, hl, wl, L), eo.w_tck_t, None, da, n=n, h=hl, w=wl, cin=L, cout=C)
         dout = nm.bwd(act, da, silu=False, dres=None, eng=self)
+        self._ready(eo.prefix[:-4], nm.prefix + ".")
         dout = self._walk_bwd(self.enc_layers, dout, saved)
         # encoder conv_in (cin -> C0): weight grads; data grad only on request
         ei = self.enc_in
@@ -409,6 +433,7 @@ class Engine:
         c0 = dout.shape[3]
         ops.wgrad_direct(dout, x, gv(ei.prefix + ".weight"), n=n, h=h, w=w, cw=c0, cn=cin, ksize=3, sgn=-1,
                          narrow_layout="nchw", dw_strides=(1, cin * 9, 9), dbias_wide=gv(ei.prefix + ".bias"))
+        self._ready("encoder.blocks.0.")
         if not want_dx:
             return None
         dx = torch.empty_like(x)
@@ -453,16 +478,19 @@ class Engine:
         da = _empty(act.t.shape, z)
         ops.conv_direct(drecon, do.w_tck_t, None, da, n=n, h=h, w=w, cin=co, cout=C, x_layout="nchw")
         dout = nm.bwd(act, da, silu=False, dres=None, eng=self)
+        self._ready(do.prefix[:-4], nm.prefix + ".")
         dout = self._walk_bwd(self.dec_layers, dout, saved)
         di = self.dec_in
         ops.wgrad_direct(dout, zq.view(n, hl, wl, L), gv(di.prefix + ".weight"), n=n, h=hl, w=wl, cw=di.cout, cn=L,
                          ksize=3, sgn=-1, narrow_layout="nhwc", dw_strides=(1, L * 9, 9),
                          dbias_wide=gv(di.prefix + ".bias"))
+        self._ready("decoder.blocks.0.")
         dzq = _empty((n, hl * wl, L), z, F32)
         ops.conv_direct(dout, di.w_tck_t, None, dzq.view(n, hl, wl, L), n=n, h=hl, w=wl, cin=di.cout, cout=L)
         wp, _ = self._qp("post_quant_conv")
         dz = torch.empty_like(z) if want_dz else None
         ops.post_quant_bwd(dzq, z, wp, dz, gv("post_quant_conv.conv.weight"), gv("post_quant_conv.conv.bias"))
+        self._ready("post_quant_conv.")
         return dz
 
     # ---- autograd entry points --------------------------------------------------------------------

@@ -111,10 +111,31 @@ def conv_mfma(x, w_packed, bias, y, *, cout, ksize=3, mode=PTI_CONV_S1, prologue
     d = ConvDesc(n=n, h=h, w=w, cin=cin, ho=ho, wo=wo, cout=cout, ksize=ksize, mode=mode, prologue=prologue,
                  groups=groups, add_residual=int(residual is not None), accum_stats=int(out_stats is not None),
                  out_groups=out_groups, eps=eps)
+    prof = KERNEL_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     L.check(L.lib().pti_conv2d_mfma(_ptr(x), _ptr(w_packed), _ptr(bias), _ptr(in_stats), _ptr(gamma), _ptr(beta),
                                     _ptr(residual), _ptr(y), _ptr(out_stats), C.byref(d), _stream()),
             "pti_conv2d_mfma")
+    if prof is not None:
+        e1.record()
+        s2 = mode == PTI_CONV_S2PAD
+        ck = 128 if cin % 128 == 0 else (64 if cin % 64 == 0 else 32)
+        ck = min(ck, 64) if s2 else ck
+        ct = 128 if cout % 128 == 0 else (64 if cout % 64 == 0 else 32)
+        name = f"conv_mfma_kernel<{ksize},{2 if s2 else 1},{ck},{ct}>"
+        # algorithmic work; the zero-insert data gradient only has 1/4 useful taps per output pixel
+        flops = 2.0 * n * ho * wo * cout * cin * ksize * ksize * (0.25 if mode == PTI_CONV_ZINS else 1.0)
+        # algorithmic bytes: read the input once (bf16), write the output once (+ residual read)
+        nbytes = 2.0 * (x.numel() + y.numel() * (2 if residual is not None else 1))
+        prof.append((name, flops, nbytes, e0, e1))
     return y
+
+
+# Set to a list to make conv_mfma record (kernel name, algorithmic flops, bytes, start, end events) per
+# launch on the current stream — used by bench.py for the roofline line; None costs nothing.
+KERNEL_PROFILE = None
 
 
 def _strides4(t, layout):
