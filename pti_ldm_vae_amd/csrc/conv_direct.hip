@@ -80,6 +80,16 @@ __global__ __launch_bounds__(256) void direct_fewcout_kernel(DArgs a) {
   const int pad = (a.KS - 1) / 2;
   const int cpg = a.prologue ? a.Cin / a.groups : 1;
   const bf16* X = (const bf16*)a.x;
+  // single-output-channel layers (decoder conv_out at full resolution) keep their 9x8 weights in registers
+  float wreg[MAXCO == 1 ? 9 : 1][8];
+  if constexpr (MAXCO == 1) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wreg[t][j] = (t < a.KS * a.KS) ? a.w[(size_t)(t * a.Cin + lc * 8 + j)] : 0.f;
+  }
+  float sc[8], sh[8];
+  int cur_n = -1;
   for (long long pix0 = (long long)blockIdx.x * ppb; pix0 < npix; pix0 += (long long)gridDim.x * ppb) {
     const long long pix = pix0 + lp;
     const bool act = pix < npix;
@@ -87,8 +97,8 @@ __global__ __launch_bounds__(256) void direct_fewcout_kernel(DArgs a) {
     const int ox = pc % a.W;
     const int oy = (pc / a.W) % a.H;
     const int n = pc / ((long long)a.W * a.H);
-    float sc[8], sh[8];
-    if (a.prologue) {
+    if (a.prologue && n != cur_n) {
+      cur_n = n;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int ch = lc * 8 + j, g = ch / cpg;
@@ -102,23 +112,34 @@ __global__ __launch_bounds__(256) void direct_fewcout_kernel(DArgs a) {
     float acc[MAXCO];
 #pragma unroll
     for (int c = 0; c < MAXCO; ++c) acc[c] = 0.f;
-    for (int kh = 0; kh < a.KS; ++kh) {
-      const int iy = oy + kh - pad;
-      for (int kw = 0; kw < a.KS; ++kw) {
-        const int ix = ox + kw - pad;
-        if (!act || iy < 0 || iy >= a.H || ix < 0 || ix >= a.W) continue;
-        const u32x4 r = *(const u32x4*)(X + ((size_t)(n * a.H + iy) * a.W + ix) * a.Cin + lc * 8);
-        float f[8];
-        unpack8(r, f);
-        if (a.prologue) {
+    u32x4 raw[9];
+    bool ok[9];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            float v = f[j] * sc[j] + sh[j];
-            if (a.prologue == PTI_PRO_GN_SILU) v = silu_f(v);
-            f[j] = v;
-          }
+    for (int t = 0; t < 9; ++t) {
+      const int kh = t / 3, kw = t % 3;
+      const int iy = oy + kh - pad, ix = ox + kw - pad;
+      ok[t] = act && kh < a.KS && kw < a.KS && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      raw[t] = u32x4{0u, 0u, 0u, 0u};
+      if (ok[t]) raw[t] = *(const u32x4*)(X + ((size_t)(n * a.H + iy) * a.W + ix) * a.Cin + lc * 8);
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      if (!ok[t]) continue;
+      float f[8];
+      unpack8(raw[t], f);
+      if (a.prologue) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float v = f[j] * sc[j] + sh[j];
+          if (a.prologue == PTI_PRO_GN_SILU) v = silu_f(v);
+          f[j] = v;
         }
-        const float* wt = a.w + ((size_t)(kh * a.KS + kw) * a.Cin + lc * 8) * a.Cout;
+      }
+      if constexpr (MAXCO == 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[0] += f[j] * wreg[t][j];
+      } else {
+        const float* wt = a.w + ((size_t)(a.KS == 3 ? t : 0) * a.Cin + lc * 8) * a.Cout;
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -163,7 +184,6 @@ struct WGArgs {
 };
 
 __global__ __launch_bounds__(256) void wgrad_direct_kernel(WGArgs a) {
-  __shared__ float red[256];  // reduction scratch
   const int NC = a.CW / 8;
   const int lc = threadIdx.x % NC, lp = threadIdx.x / NC;
   const int ppb = 256 / NC;
@@ -174,6 +194,8 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(WGArgs a) {
   float acc[9][8];
   float bsum[8];
   float nsum = 0.f;
+  float sc[8], sh[8];
+  int cur_n = -1;
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -188,8 +210,8 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(WGArgs a) {
     const int n = pix / ((long long)a.W * a.H);
     const float nv = ld_narrow(a.narrow, n * a.ns[0] + oy * a.ns[1] + ox * a.ns[2] + k * a.ns[3], a.narrow_f32);
     nsum += nv;
-    float sc[8], sh[8];
-    if (a.prologue) {
+    if (a.prologue && n != cur_n) {
+      cur_n = n;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int ch = lc * 8 + j, g = ch / cpg;
@@ -229,42 +251,43 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(WGArgs a) {
       }
     }
   }
-  // block reduction over the ppb pixel-lanes that share lc: through LDS in 4 passes of 18 values
+  // reduction: (1) across the lanes of a wave that share lc (stride NC) by shuffles, (2) across the
+  // 4 waves through LDS, (3) one atomicAdd per output element and block.
+  extern __shared__ float red[];  // [4][80][NC]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int ntap = a.KS * a.KS;
-  for (int t = 0; t < ntap; ++t) {
+  auto wred = [&](float v) {
+    for (int o = 32; o >= NC; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  };
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float v = acc[t][j];
-      // lanes with equal lc are NC apart: reduce across lp
-      red[threadIdx.x] = v;
-      __syncthreads();
-      for (int s = 128; s >= NC; s >>= 1) {
-        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-        __syncthreads();
-      }
-      if (threadIdx.x < NC)
-        atomicAdd(&a.dw[t * a.dw_stride_tap + (threadIdx.x * 8 + j) * a.dw_stride_cw + k * a.dw_stride_k], red[threadIdx.x]);
-      __syncthreads();
+      const float v = wred(acc[t][j]);
+      if (lane < NC) red[(wave * 80 + t * 8 + j) * NC + lane] = v;
     }
-  }
-  if (a.dbias_wide && k == 0) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      red[threadIdx.x] = bsum[j];
-      __syncthreads();
-      for (int s = 128; s >= NC; s >>= 1) {
-        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-        __syncthreads();
-      }
-      if (threadIdx.x < NC) atomicAdd(&a.dbias_wide[threadIdx.x * 8 + j], red[threadIdx.x]);
-      __syncthreads();
+  for (int j = 0; j < 8; ++j) {
+    const float v = wred(bsum[j]);
+    if (lane < NC) red[(wave * 80 + 72 + j) * NC + lane] = v;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 80 * NC; e += 256) {
+    const int vi = e / NC, c = e % NC;
+    const float v = red[e] + red[80 * NC + e] + red[2 * 80 * NC + e] + red[3 * 80 * NC + e];
+    if (vi < 72) {
+      const int t = vi / 8, j = vi % 8;
+      if (t < ntap) atomicAdd(&a.dw[t * a.dw_stride_tap + (c * 8 + j) * a.dw_stride_cw + k * a.dw_stride_k], v);
+    } else if (a.dbias_wide && k == 0) {
+      atomicAdd(&a.dbias_wide[c * 8 + (vi - 72)], v);
     }
   }
   if (a.dbias_narrow) {
     // every NC-th lane carries a distinct pixel's narrow value: count each pixel once (lc == 0)
     float v = (lc == 0) ? nsum : 0.f;
     v = wave_sum(v);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&a.dbias_narrow[k], v);
+    if (lane == 0) atomicAdd(&a.dbias_narrow[k], v);
   }
 }
 
@@ -302,7 +325,9 @@ extern "C" int pti_conv2d_direct(const void* x, const float* w, const float* bia
     const int ppb = 256 / (d->cin / 8);
     long long blocks = (npix + ppb - 1) / ppb;
     if (blocks > 65536) blocks = 65536;
-    if (d->cout <= 4) hipLaunchKernelGGL(direct_fewcout_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, a);
+    if (blocks > 2048) blocks = 2048;
+    if (d->cout == 1) hipLaunchKernelGGL(direct_fewcout_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, a);
+    else if (d->cout <= 4) hipLaunchKernelGGL(direct_fewcout_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, a);
     else hipLaunchKernelGGL(direct_fewcout_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, a);
   } else {
     PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_direct: cin=%d cout=%d is not a degenerate-channel shape", d->cin, d->cout);
@@ -317,7 +342,7 @@ extern "C" int pti_wgrad_direct(const void* wide, const void* narrow, float* dw,
                                 float eps, int narrow_f32, const int64_t* narrow_stride, int64_t dw_stride_tap,
                                 int64_t dw_stride_cw, int64_t dw_stride_k, pti_stream_t s) {
   if (!wide || !narrow || !dw || !narrow_stride) PTI_FAIL(PTI_EINVAL, "wgrad_direct: null pointer");
-  if (cw % 8 || cw < 8 || cw > 512 || (cw & (cw - 1)) || cn <= 0 || (ksize != 1 && ksize != 3))
+  if (cw % 8 || cw < 8 || cw > 256 || (cw & (cw - 1)) || cn <= 0 || (ksize != 1 && ksize != 3))
     PTI_FAIL(PTI_EUNSUPPORTED, "wgrad_direct: cw=%d cn=%d k=%d", cw, cn, ksize);
   if (prologue && (!in_stats || !gamma || !beta || groups <= 0 || cw % groups)) PTI_FAIL(PTI_EINVAL, "wgrad_direct: prologue args");
   WGArgs a;
@@ -332,8 +357,9 @@ extern "C" int pti_wgrad_direct(const void* wide, const void* narrow, float* dw,
   const long long npix = (long long)n * h * w;
   const int ppb = 256 / (cw / 8);
   long long blocks = (npix + ppb - 1) / ppb;
-  if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(wgrad_direct_kernel, dim3((unsigned)blocks, cn), dim3(256), 0, (hipStream_t)s, a);
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(wgrad_direct_kernel, dim3((unsigned)blocks, cn), dim3(256), 4 * 80 * (cw / 8) * sizeof(float),
+                     (hipStream_t)s, a);
   PTI_CHECK_LAUNCH("wgrad_direct");
   return PTI_OK;
 }

@@ -52,20 +52,28 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16* __restrict__ 
     }
   }
   const int cpg = C / G;
-  if (cpg >= 8) {
-    float a = 0.f, b = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { a += s[j]; b += q[j]; }
-    const int g = (lc * 8) / cpg;
-    atomicAdd(&sm[2 * g], a);
-    atomicAdd(&sm[2 * g + 1], b);
-  } else {
-    for (int j0 = 0; j0 < 8; j0 += cpg) {
+  for (int j = 0; j < 8; ++j)
+    for (int o = 32; o >= NC; o >>= 1) {   // fold the lanes of this wave that hold the same channels
+      s[j] += __shfl_xor(s[j], o, 64);
+      q[j] += __shfl_xor(q[j], o, 64);
+    }
+  if ((tid & 63) < NC || NC > 64) {
+    if (cpg >= 8) {
       float a = 0.f, b = 0.f;
-      for (int j = j0; j < j0 + cpg; ++j) { a += s[j]; b += q[j]; }
-      const int g = (lc * 8 + j0) / cpg;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { a += s[j]; b += q[j]; }
+      const int g = (lc * 8) / cpg;
       atomicAdd(&sm[2 * g], a);
       atomicAdd(&sm[2 * g + 1], b);
+    } else {
+      for (int j0 = 0; j0 < 8; j0 += cpg) {
+        float a = 0.f, b = 0.f;
+        for (int j = j0; j < j0 + cpg; ++j) { a += s[j]; b += q[j]; }
+        const int g = (lc * 8 + j0) / cpg;
+        atomicAdd(&sm[2 * g], a);
+        atomicAdd(&sm[2 * g + 1], b);
+      }
     }
   }
   __syncthreads();
@@ -134,22 +142,45 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnbArgs a) {
   for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
   const int p0 = blockIdx.x * a.ppb, p1 = min(p0 + a.ppb, a.HW);
   const size_t base = (size_t)n * a.HW * a.C + lc * 8;
-  for (int p = p0 + lp; p < p1; p += ppi) {
-    float fx[8], fd[8];
-    unpack8(*(const u32x4*)(a.x + base + (size_t)p * a.C), fx);
-    unpack8(*(const u32x4*)(a.da + base + (size_t)p * a.C), fd);
+  constexpr int U = 4;  // independent 16-byte loads in flight per tensor and thread
+  for (int pb = p0 + lp; pb < p1; pb += U * ppi) {
+    u32x4 rx[U], rd[U];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float dy = fd[j];
-      if (a.silu) dy *= dsilu_f(fx[j] * sc[j] + sh[j]);
-      s1[j] += dy;
-      s2[j] += dy * (fx[j] - mu[j]) * rs[j];
+    for (int u = 0; u < U; ++u) {
+      const int p = pb + u * ppi;
+      rx[u] = rd[u] = u32x4{0u, 0u, 0u, 0u};
+      if (p < p1) {
+        rx[u] = *(const u32x4*)(a.x + base + (size_t)p * a.C);
+        rd[u] = *(const u32x4*)(a.da + base + (size_t)p * a.C);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float fx[8], fd[8];
+      unpack8(rx[u], fx);
+      unpack8(rd[u], fd);   // da == 0 for the padded lanes => they add nothing
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float dy = fd[j];
+        if (a.silu) dy *= dsilu_f(fx[j] * sc[j] + sh[j]);
+        s1[j] += dy;
+        s2[j] += dy * (fx[j] - mu[j]) * rs[j];
+      }
     }
   }
+  // lanes lc, lc+NC, lc+2NC, ... of a wave hold the same channels: fold them with shuffles first so
+  // that only NC lanes per wave touch the LDS accumulators (256 contended LDS atomics -> 4 per address)
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    atomicAdd(&sm[(lc * 8 + j) * 2], s1[j]);
-    atomicAdd(&sm[(lc * 8 + j) * 2 + 1], s2[j]);
+    float v1 = s1[j], v2 = s2[j];
+    for (int o = 32; o >= NC; o >>= 1) {
+      v1 += __shfl_xor(v1, o, 64);
+      v2 += __shfl_xor(v2, o, 64);
+    }
+    if ((tid & 63) < NC || NC > 64) {
+      atomicAdd(&sm[(lc * 8 + j) * 2], v1);
+      atomicAdd(&sm[(lc * 8 + j) * 2 + 1], v2);
+    }
   }
   __syncthreads();
   for (int i = tid; i < a.C; i += 256) {
@@ -186,22 +217,35 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnbArgs a) {
   }
   const int p0 = blockIdx.x * a.ppb, p1 = min(p0 + a.ppb, a.HW);
   const size_t base = (size_t)n * a.HW * a.C + lc * 8;
-  for (int p = p0 + lp; p < p1; p += ppi) {
-    float fx[8], fd[8], fr[8];
-    unpack8(*(const u32x4*)(a.x + base + (size_t)p * a.C), fx);
-    unpack8(*(const u32x4*)(a.da + base + (size_t)p * a.C), fd);
-    if (a.dres) unpack8(*(const u32x4*)(a.dres + base + (size_t)p * a.C), fr);
-    float o[8];
+  constexpr int U = 4;
+  for (int pb = p0 + lp; pb < p1; pb += U * ppi) {
+    u32x4 rx[U], rd[U], rr[U];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float dy = fd[j];
-      if (a.silu) dy *= dsilu_f(fx[j] * sc[j] + sh[j]);
-      const float xh = (fx[j] - mu[j]) * rs[j];
-      float v = rs[j] * (ga[j] * dy - c1[j] - xh * c2[j]);
-      if (a.dres) v += fr[j];
-      o[j] = v;
+    for (int u = 0; u < U; ++u) {
+      const int p = pb + u * ppi;
+      rx[u] = rd[u] = rr[u] = u32x4{0u, 0u, 0u, 0u};
+      if (p < p1) {
+        rx[u] = *(const u32x4*)(a.x + base + (size_t)p * a.C);
+        rd[u] = *(const u32x4*)(a.da + base + (size_t)p * a.C);
+        if (a.dres) rr[u] = *(const u32x4*)(a.dres + base + (size_t)p * a.C);
+      }
     }
-    *(u32x4*)(a.dx + base + (size_t)p * a.C) = pack8(o);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = pb + u * ppi;
+      float fx[8], fd[8], fr[8], o[8];
+      unpack8(rx[u], fx);
+      unpack8(rd[u], fd);
+      unpack8(rr[u], fr);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float dy = fd[j];
+        if (a.silu) dy *= dsilu_f(fx[j] * sc[j] + sh[j]);
+        const float xh = (fx[j] - mu[j]) * rs[j];
+        o[j] = rs[j] * (ga[j] * dy - c1[j] - xh * c2[j]) + fr[j];
+      }
+      if (p < p1) *(u32x4*)(a.dx + base + (size_t)p * a.C) = pack8(o);
+    }
   }
 }
 

@@ -56,8 +56,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgArgs a) {
   unsigned char* lD = smem + C::A_BYTES;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int split = blockIdx.x;
-  const int cot = blockIdx.y / a.ci_tiles, cit = blockIdx.y % a.ci_tiles;
+  const int split = blockIdx.y;  // (co,ci) tiles of one pixel split are adjacent in dispatch order: shared L2 lines
+  const int cot = blockIdx.x / a.ci_tiles, cit = blockIdx.x % a.ci_tiles;
   const int wco = wave / (C::WCI * C::WPX), wci = (wave / C::WPX) % C::WCI, wpx = wave % C::WPX;
 
   const int pad_lo = (a.mode == PTI_CONV_S2PAD) ? 0 : (KS - 1) / 2;
@@ -279,7 +279,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, long long st
 
 template <int KS, int S_, int CO_T, int CI_T>
 void launch_w(const WgArgs& a, int grid_y, hipStream_t st) {
-  hipLaunchKernelGGL((wgrad_mfma_kernel<KS, S_, CO_T, CI_T>), dim3(a.S, grid_y), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((wgrad_mfma_kernel<KS, S_, CO_T, CI_T>), dim3(grid_y, a.S), dim3(256), 0, st, a);
 }
 template <int KS, int S_>
 void launch_wt(const WgArgs& a, int co_t, int ci_t, int grid_y, hipStream_t st) {
@@ -311,15 +311,20 @@ extern "C" int pti_conv_wgrad_mfma(const void* x, const void* dy, const float* i
   a.mode = d->mode; a.prologue = d->prologue; a.groups = d->groups; a.eps = d->eps;
   a.inv_cnt = d->prologue != PTI_PRO_NONE ? 1.0f / ((float)(d->cin / d->groups) * (float)d->h * (float)d->w) : 0.f;
   a.tiles_x = cdiv(d->wo, TW); a.tiles_y = cdiv(d->ho, TH); a.ntiles = d->n * a.tiles_x * a.tiles_y;
-  const int co_t = d->cout % 64 == 0 ? 64 : 32, ci_t = d->cin % 64 == 0 ? 64 : 32;
+  // Tile / split choice: 64x64 (co,ci) tiles only when every workgroup still gets >= 16 pixel tiles at ~512
+  // workgroups; otherwise 32x32 tiles (4 waves split the pixels) so that fewer, longer splits are needed and
+  // the partial-slab traffic (S x full dW) stays small.
+  int co_t = d->cout % 64 == 0 ? 64 : 32, ci_t = d->cin % 64 == 0 ? 64 : 32;
+  if ((long long)a.ntiles * (d->cout / co_t) * (d->cin / ci_t) < 16 * 512) co_t = ci_t = 32;
   a.ci_tiles = d->cin / ci_t;
   const int tiles_cc = (d->cout / co_t) * a.ci_tiles;
   const int kk = d->ksize * d->ksize;
   a.slab_stride = (long long)kk * d->cout * d->cin + d->cout;
   long long smax = workspace_bytes / (a.slab_stride * 4);
   int S = 512 / tiles_cc;
+  if (S > a.ntiles / 4) S = a.ntiles / 4;
+  if (S > 256) S = 256;
   if (S < 1) S = 1;
-  if (S > a.ntiles) S = a.ntiles;
   if (S > smax) S = (int)smax;
   if (S < 1) PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma: workspace too small (%lld bytes per split needed)", a.slab_stride * 4);
   a.S = S;

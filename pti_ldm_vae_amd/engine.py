@@ -122,7 +122,7 @@ class _Norm:
     def bwd(self, x, da, *, silu, dres, eng):
         n, h, w, c = x.t.shape
         dx = _empty(x.t.shape, x.t)
-        sums = torch.zeros(n, c, 2, dtype=F32, device=x.t.device)
+        sums = eng.zeros(n * c * 2)
         ops.gn_bwd(x.t, da, dx, x.stats, self.weight.data, self.bias.data, sums,
                    self.net.grad_view(self.prefix + ".weight"), self.net.grad_view(self.prefix + ".bias"),
                    groups=eng.G, eps=eng.eps, silu=silu, dres=dres)
@@ -269,6 +269,7 @@ class Engine:
         self.packed_version = -1
         self.grad_ready_cb = None
         self._range_cache = {}
+        self._zpool, self._zoff, self._zpool_size = None, 0, 1 << 16
         ops.L.lib()  # fail loudly now if the HIP extension is missing
         for c in net.channels:
             if c % 32:
@@ -310,7 +311,23 @@ class Engine:
 
     # ---- helpers -------------------------------------------------------------------------------
     def new_stats(self, n):
-        return torch.zeros(n, self.G, 2, dtype=F32, device=self.dev)
+        return self.zeros(n * self.G * 2).view(n, self.G, 2)
+
+    def zeros(self, count):
+        """Zero-initialised fp32 scratch carved from one pool per pass (one memset instead of ~100 fills)."""
+        count = (count + 3) // 4 * 4
+        pool = self._zpool
+        if pool is None or self._zoff + count > pool.numel():
+            pool = self._zpool = torch.zeros(max(count, self._zpool_size), dtype=F32, device=self.dev)
+            self._zoff = 0
+        out = pool[self._zoff:self._zoff + count]
+        self._zoff += count
+        return out
+
+    def begin_pass(self, batch, backward=False):
+        cmax = max(self.net.channels)
+        self._zpool_size = (64 * batch * cmax * 2) if backward else (96 * batch * self.G * 2)
+        self._zpool = None
 
     def refresh_weights(self):
         """Re-derive the bf16 MFMA-packed / transposed operands when the fp32 masters changed."""
@@ -375,10 +392,11 @@ class Engine:
         down = 2 ** (len(self.net.channels) - 1)
         if h % down or w % down:
             raise ValueError(f"encode: H,W must be multiples of {down}, got {h}x{w}")
+        self.begin_pass(n)
         c0 = self.net.channels[0]
         t0 = _empty((n, h, w, c0), x)
         ops.conv_direct(x, self.enc_in.w_tck, self.enc_in.b.data, t0, n=n, h=h, w=w, cin=cin, cout=c0, x_layout="nchw")
-        a0 = _Act(t0, ops.gn_stats(t0, self.G))
+        a0 = _Act(t0, ops.gn_stats(t0, self.G, self.new_stats(n)))
         saved = [] if save else None
         act = self._walk_fwd(self.enc_layers, a0, True, saved)
         hl, wl, L = act.t.shape[1], act.t.shape[2], self.Lc
@@ -405,9 +423,10 @@ class Engine:
         wm, bm = self._qp("quant_conv_mu")
         wl_, bl = self._qp("quant_conv_log_sigma")
         wp, bp = self._qp("post_quant_conv")
+        self.begin_pass(n, backward=True)
         dh = torch.empty_like(hlat)
         gv = net.grad_view
-        scratch = torch.zeros(L * L + L, dtype=F32, device=self.dev)   # post_quant grads are not produced here
+        scratch = self.zeros(L * L + L)   # post_quant grads are not produced here
         ops.latent_head_bwd(hlat, None, wm, bm, wl_, bl, wp, bp, None,
                             None if dmu is None else dmu.contiguous().float(),
                             None if dsigma is None else dsigma.contiguous().float(), dh,
@@ -445,13 +464,14 @@ class Engine:
         self.refresh_weights()
         z = self._check_input(z, self.Lc, "decode")
         n, L, hl, wl = z.shape
+        self.begin_pass(n)
         wp, bp = self._qp("post_quant_conv")
         zq = _empty((n, hl * wl, L), z, F32)
         ops.post_quant(z, wp, bp, zq)
         di = self.dec_in
         t0 = _empty((n, hl, wl, di.cout), z)
         ops.conv_direct(zq.view(n, hl, wl, L), di.w_tck, di.b.data, t0, n=n, h=hl, w=wl, cin=L, cout=di.cout)
-        a0 = _Act(t0, ops.gn_stats(t0, self.G))
+        a0 = _Act(t0, ops.gn_stats(t0, self.G, self.new_stats(n)))
         saved = [] if save else None
         act = self._walk_fwd(self.dec_layers, a0, True, saved)
         h, w, C = act.t.shape[1], act.t.shape[2], act.t.shape[3]
@@ -467,6 +487,7 @@ class Engine:
         z, zq, a0, saved, act = ctx
         net, gv = self.net, self.net.grad_view
         n, L, hl, wl = z.shape
+        self.begin_pass(n, backward=True)
         drecon = drecon.contiguous().float()
         do, nm = self.dec_out, self.dec_out.norm
         h, w, C = act.t.shape[1], act.t.shape[2], act.t.shape[3]
