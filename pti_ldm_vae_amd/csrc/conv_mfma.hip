@@ -324,6 +324,346 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
   }
 }
 
+// =============================================================================================
+// v2 kernel (stride-1 gathers: PTI_CONV_S1 / UP2 / ZINS, k in {1,3}).
+// Measured on v1: LDS was the bottleneck (weights written to + read from LDS every step, one barrier
+// per step).  v2 keeps ONLY the halo tile in LDS.  Each wave owns 128 pixels (4 MFMA pixel fragments)
+// x 32 output channels, and streams its weight fragments straight from global/L2 into an 8-deep
+// register ring (the packed layout makes every fragment one coalesced 1-KiB wave load), so the main
+// loop has no LDS writes and no barriers; 4 MFMAs are issued per 4 ds_read_b128 + 1 global load.
+// Workgroup = 4 waves = (4/WN) pixel groups x WN cout fragments, i.e. 128*WM pixels x CT channels.
+// =============================================================================================
+__host__ __device__ constexpr int pick_ck2(int cin, int ct) {
+  const int ck = cin % 128 == 0 ? 128 : (cin % 64 == 0 ? 64 : 32);
+  const int cap = ct >= 128 ? 128 : (ct == 64 ? 64 : 32);   // keep the halo tile <= ~48 KiB
+  return ck < cap ? ck : cap;
+}
+
+template <int KS, int CK, int CT>
+struct Cfg2 {
+  static constexpr int WN = CT / 32, WM = 4 / WN;
+  static constexpr int TH2 = 8 * WM, TW2 = 16;
+  static constexpr int HH = TH2 + KS - 1, HW = TW2 + KS - 1;
+  static constexpr int NP = HH * HW;
+  static constexpr int NC = CK / 8;
+  static constexpr int PIXB = CK * 2;
+  static constexpr int NT = CT / 32;
+  static constexpr int KPC = CK / 16;
+  static constexpr int KBC = KS * KS * KPC;
+  static constexpr int R = (KS == 3) ? 9 : KBC;   // register ring depth; always divides KBC
+  static constexpr int HALO_BYTES = NP * PIXB;
+  static constexpr int KEY_SHIFT = (NC == 16) ? 0 : (NC == 8 ? 1 : 2);
+  static constexpr int HITERS = (NP * NC + 255) / 256;
+  // epilogue: the 128*WM x CT output tile is transposed through LDS ([pixel][CT] bf16, padded pitch) so that
+  // global stores / residual loads are 16-byte pieces with consecutive lanes on consecutive addresses
+  static constexpr int MPX = 128 * WM;
+  static constexpr int EPITCH = CT * 2 + 16;
+  static constexpr int EPI_BYTES = MPX * EPITCH;
+  static constexpr int ENC = CT / 8;                      // 16-byte pieces per pixel of the tile
+  static constexpr int EITERS = MPX * ENC / 256;
+  static constexpr int STAT_OFF = HALO_BYTES > EPI_BYTES ? HALO_BYTES : EPI_BYTES;   // 256 floats of group sums
+  static constexpr int LDS_BYTES = STAT_OFF + 1024;
+};
+
+template <int KS, int CK, int CT>
+__global__ __launch_bounds__(256, 2) void conv_mfma2_kernel(ConvArgs a) {
+  using C = Cfg2<KS, CK, CT>;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS_BYTES];
+  unsigned char* halo = smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hsel = lane >> 5;
+  int t = blockIdx.x;
+  const int tile_x = t % a.tiles_x;
+  t /= a.tiles_x;
+  const int tile_y = t % a.tiles_y;
+  const int n = t / a.tiles_y;
+  const int oy0 = tile_y * C::TH2, ox0 = tile_x * C::TW2;
+  const int ct = blockIdx.y;
+  const int nchunks = a.Cin / CK;
+  const int wm = wave / C::WN, wn = wave % C::WN;
+
+  const int pad_lo = (a.mode == PTI_CONV_ZINS) ? 2 : (KS - 1) / 2;
+  const int vy0 = oy0 - pad_lo, vx0 = ox0 - pad_lo;
+  const bool twox = (a.mode == PTI_CONV_UP2) || (a.mode == PTI_CONV_ZINS);
+  const int VH = twox ? 2 * a.H : a.H, VW = twox ? 2 * a.W : a.W;
+
+  // per-lane LDS addresses of the pixel (B) fragments: fragment i = tile rows 8*wm + 2i, +1
+  int pbase[KS], tkey[KS];
+  {
+    const int j = lane & 31, tx = j & 15, row0 = 8 * wm + (j >> 4);
+#pragma unroll
+    for (int kw = 0; kw < KS; ++kw) {
+      const int hx = tx + kw;
+      tkey[kw] = (hsel ^ ((hx >> C::KEY_SHIFT) & (C::NC - 1))) << 4;
+      pbase[kw] = (row0 * C::HW + hx) * C::PIXB;
+    }
+  }
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  const int lc = tid % C::NC, lp0 = tid / C::NC;
+  constexpr int PSTEP = 256 / C::NC;
+  const int cpg = a.Cin / (a.groups > 0 ? a.groups : 1);
+  reinterpret_cast<float*>(smem + C::STAT_OFF)[tid] = 0.f;   // visible after the first barrier below
+
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    // weight fragments of this (cout tile, cin chunk): [kb][nt][lane][8]; start the ring first so the
+    // loads fly while the halo tile is staged
+    const unsigned char* wlane =
+        a.w + ((size_t)(ct * nchunks + chunk) * C::KBC * C::NT + wn) * 1024 + lane * 16;
+    // two alternating register sets of R weight fragments: set A is consumed while set B (the next group of
+    // R k-blocks) is in flight, so every global load has a whole group (R x 4 MFMAs) to land
+    bf16x8 wa[C::R], wb[C::R];
+    auto wload = [&](bf16x8 (&dst)[C::R], int g) {
+#pragma unroll
+      for (int u = 0; u < C::R; ++u) {
+        int kb = g * C::R + u;
+        kb = kb < C::KBC ? kb : C::KBC - 1;
+        dst[u] = *(const bf16x8*)(wlane + (size_t)kb * C::NT * 1024);
+      }
+    };
+    wload(wa, 0);
+
+    float sc[8], sh[8];
+    if (a.prologue != PTI_PRO_NONE) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int ch = chunk * CK + lc * 8 + j;
+        const int g = ch / cpg;
+        const float sum = a.in_stats[(n * a.groups + g) * 2], sq = a.in_stats[(n * a.groups + g) * 2 + 1];
+        const float mean = sum * a.inv_cnt;
+        const float rstd = rsqrtf(fmaxf(sq * a.inv_cnt - mean * mean, 0.f) + a.eps);
+        sc[j] = rstd * a.gamma[ch];
+        sh[j] = a.beta[ch] - mean * sc[j];
+      }
+    }
+    u32x4 raw[C::HITERS];
+    bool ok[C::HITERS];
+#pragma unroll
+    for (int it = 0; it < C::HITERS; ++it) {
+      const int p = lp0 + it * PSTEP;
+      const int hy = p / C::HW, hx = p - hy * C::HW;
+      const int vy = vy0 + hy, vx = vx0 + hx;
+      bool v = (p < C::NP) && vy >= 0 && vy < VH && vx >= 0 && vx < VW;
+      int iy = vy, ix = vx;
+      if (twox) {
+        if (a.mode == PTI_CONV_ZINS) v = v && !((vy | vx) & 1);
+        iy = vy >> 1;
+        ix = vx >> 1;
+      }
+      ok[it] = v;
+      raw[it] = u32x4{0u, 0u, 0u, 0u};
+      if (v) raw[it] = *(const u32x4*)(a.x + ((size_t)(n * a.H + iy) * a.W + ix) * a.Cin + chunk * CK + lc * 8);
+    }
+    if (chunk > 0) __syncthreads();  // every wave is done reading the previous chunk's halo
+#pragma unroll
+    for (int it = 0; it < C::HITERS; ++it) {
+      const int p = lp0 + it * PSTEP;
+      if (p < C::NP) {
+        const int hy = p / C::HW, hx = p - hy * C::HW;
+        u32x4 r = raw[it];
+        if (a.prologue != PTI_PRO_NONE && ok[it]) {
+          float f[8];
+          unpack8(r, f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float v = f[j] * sc[j] + sh[j];
+            if (a.prologue == PTI_PRO_GN_SILU) v = silu_f(v);
+            f[j] = v;
+          }
+          r = pack8(f);
+        }
+        const int key = (hx >> C::KEY_SHIFT) & (C::NC - 1);
+        *(u32x4*)(halo + p * C::PIXB + ((lc ^ key) << 4)) = r;
+      }
+    }
+    __syncthreads();
+
+    // main loop over groups of R k-blocks.  B (pixel) fragments are double-buffered in registers: the 4
+    // ds_read_b128 of k-block u+1 are issued before the 4 MFMAs of k-block u.
+    const int txl = lane & 15;
+    auto baddr = [&](int kb) -> const unsigned char* {
+      kb = kb < C::KBC ? kb : C::KBC - 1;
+      const int tap = kb / C::KPC, kc = kb - tap * C::KPC;
+      const int kh = (KS == 3) ? tap / 3 : 0, kw = tap - kh * KS;
+      const int hx = txl + kw;
+      const int tk = (hsel ^ ((hx >> C::KEY_SHIFT) & (C::NC - 1))) << 4;
+      return halo + pbase[0] + (kh * C::HW + kw) * C::PIXB + ((kc * 32) ^ tk);
+    };
+    bf16x8 b0[4], b1[4];
+    auto bread = [&](bf16x8 (&dst)[4], int kb) {
+      const unsigned char* bp = baddr(kb);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dst[i] = *(const bf16x8*)(bp + 2 * i * C::HW * C::PIXB);
+    };
+    auto group = [&](const bf16x8 (&w)[C::R], int g) {
+      const int kb0 = g * C::R;
+#pragma unroll
+      for (int u = 0; u < C::R; ++u) {
+        if ((u & 1) == 0) {
+          bread(b1, kb0 + u + 1);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[u], b0[i], acc[i], 0, 0, 0);
+        } else {
+          bread(b0, kb0 + u + 1);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[u], b1[i], acc[i], 0, 0, 0);
+        }
+      }
+      if (C::R & 1) {  // odd group length: the last read went to b1/b0 alternately; realign so b0 is current
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b0[i] = b1[i];
+      }
+    };
+    constexpr int NG = C::KBC / C::R;
+    bread(b0, 0);
+    if constexpr (NG == 1) {
+      group(wa, 0);
+    } else {
+#pragma clang loop unroll(disable)
+      for (int g = 0; g < NG; g += 2) {
+        wload(wb, g + 1);
+        group(wa, g);
+        wload(wa, g + 2);
+        group(wb, g + 1);
+      }
+    }
+  }
+
+  // ---- epilogue: bias, residual, bf16 rounding, optional GroupNorm statistics, coalesced store ----
+  const int j = lane & 31;
+  unsigned char* etile = smem;
+  const bool do_stats = a.out_stats != nullptr;
+  const int ocpg = do_stats ? a.Cout / a.out_groups : 1;
+  __syncthreads();  // every wave is done with the halo tile
+  // (A) residual tile -> LDS with coalesced 16-byte loads
+  const int epc = tid % C::ENC, epp0 = tid / C::ENC;
+  constexpr int EPSTEP = 256 / C::ENC;
+  if (a.res) {
+#pragma unroll
+    for (int it = 0; it < C::EITERS; ++it) {
+      const int p = epp0 + it * EPSTEP;
+      const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
+      u32x4 r = u32x4{0u, 0u, 0u, 0u};
+      if (oy < a.Ho && ox < a.Wo)
+        r = *(const u32x4*)(a.res + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.Cout + ct * CT + epc * 8);
+      *(u32x4*)(etile + p * C::EPITCH + epc * 16) = r;
+    }
+    __syncthreads();
+  }
+  // (B) registers -> (+bias, +residual) -> bf16 -> LDS tile; statistics accumulate in-lane over the 4 fragments
+  float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f};   // per quad q (or first pair when ocpg==2)
+  float su1[4] = {0.f, 0.f, 0.f, 0.f}, su2[4] = {0.f, 0.f, 0.f, 0.f};   // second pair of the quad when ocpg==2
+  const int col0 = wn * 32 + 4 * hsel;   // channel within the CT tile
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = (8 * wm + 2 * i + (j >> 4)) * 16 + (j & 15);
+    const bool inb = (oy0 + (p >> 4) < a.Ho) && (ox0 + (p & 15) < a.Wo);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int col = col0 + 8 * q;
+      float v0 = acc[i][4 * q + 0], v1 = acc[i][4 * q + 1], v2 = acc[i][4 * q + 2], v3 = acc[i][4 * q + 3];
+      if (a.bias) {
+        const f32x4 b = *(const f32x4*)(a.bias + ct * CT + col);
+        v0 += b[0]; v1 += b[1]; v2 += b[2]; v3 += b[3];
+      }
+      unsigned char* ep = etile + p * C::EPITCH + col * 2;
+      if (a.res) {
+        const u32x2 rr = *(const u32x2*)ep;
+        v0 += __uint_as_float(rr[0] << 16);
+        v1 += __uint_as_float(rr[0] & 0xffff0000u);
+        v2 += __uint_as_float(rr[1] << 16);
+        v3 += __uint_as_float(rr[1] & 0xffff0000u);
+      }
+      const u32x2 packed = pack4(v0, v1, v2, v3);
+      *(u32x2*)ep = packed;
+      if (do_stats && inb) {
+        const float r0 = __uint_as_float(packed[0] << 16), r1 = __uint_as_float(packed[0] & 0xffff0000u);
+        const float r2 = __uint_as_float(packed[1] << 16), r3 = __uint_as_float(packed[1] & 0xffff0000u);
+        if (ocpg >= 4) {
+          st1[q] += (r0 + r1) + (r2 + r3);
+          st2[q] += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
+        } else {
+          st1[q] += r0 + r1; st2[q] += r0 * r0 + r1 * r1;
+          su1[q] += r2 + r3; su2[q] += r2 * r2 + r3 * r3;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // (C) LDS tile -> global, 16 bytes per lane, consecutive lanes on consecutive addresses
+#pragma unroll
+  for (int it = 0; it < C::EITERS; ++it) {
+    const int p = epp0 + it * EPSTEP;
+    const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
+    if (oy < a.Ho && ox < a.Wo)
+      *(u32x4*)(a.y + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.Cout + ct * CT + epc * 8) =
+          *(const u32x4*)(etile + p * C::EPITCH + epc * 16);
+  }
+  if (do_stats) {
+    // fold the 32 pixel-lanes of each half wave, then one atomic per (wave, group) straight to global
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) {
+        st1[q] += __shfl_xor(st1[q], o, 64);
+        st2[q] += __shfl_xor(st2[q], o, 64);
+        if (ocpg < 4) {
+          su1[q] += __shfl_xor(su1[q], o, 64);
+          su2[q] += __shfl_xor(su2[q], o, 64);
+        }
+      }
+    }
+    float* sstat = reinterpret_cast<float*>(smem + C::STAT_OFF);   // zeroed before the main loop
+    if (j == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co = ct * CT + col0 + 8 * q;
+        if (ocpg >= 4) {
+          const int g = co / ocpg;
+          atomicAdd(&sstat[2 * g], st1[q]);
+          atomicAdd(&sstat[2 * g + 1], st2[q]);
+        } else {
+          const int g = co / 2;
+          atomicAdd(&sstat[2 * g], st1[q]);
+          atomicAdd(&sstat[2 * g + 1], st2[q]);
+          atomicAdd(&sstat[2 * g + 2], su1[q]);
+          atomicAdd(&sstat[2 * g + 3], su2[q]);
+        }
+      }
+    }
+    __syncthreads();
+    const int g0 = (ct * CT) / ocpg, ng = CT / ocpg;   // one wave-instruction of global atomics per workgroup
+    if (tid < 2 * ng) atomicAdd(&a.out_stats[(n * a.out_groups + g0) * 2 + tid], sstat[2 * g0 + tid]);
+  }
+}
+
+template <int KS, int CK, int CT>
+int launch2_cfg(ConvArgs a, hipStream_t st) {
+  using C = Cfg2<KS, CK, CT>;
+  a.tiles_x = cdiv(a.Wo, C::TW2);
+  a.tiles_y = cdiv(a.Ho, C::TH2);
+  dim3 grid(a.N * a.tiles_x * a.tiles_y, a.Cout / CT);
+  hipLaunchKernelGGL((conv_mfma2_kernel<KS, CK, CT>), grid, dim3(256), 0, st, a);
+  return 0;
+}
+template <int KS>
+int launch2(const ConvArgs& a, int ck, int ct, hipStream_t st) {
+  if (ct == 128) {
+    if (ck == 128) return launch2_cfg<KS, 128, 128>(a, st);
+    if (ck == 64) return launch2_cfg<KS, 64, 128>(a, st);
+    return launch2_cfg<KS, 32, 128>(a, st);
+  }
+  if (ct == 64) {
+    if (ck == 64) return launch2_cfg<KS, 64, 64>(a, st);
+    return launch2_cfg<KS, 32, 64>(a, st);
+  }
+  return launch2_cfg<KS, 32, 32>(a, st);
+}
+
 // ---------------------------------------------------------------------------------------------
 // weight packing: fp32 OIHW -> bf16 [cout tile][cin chunk][k-block][nt][lane][8]
 // ---------------------------------------------------------------------------------------------
@@ -380,10 +720,8 @@ int launch_ct(const ConvArgs& a, int cout_tile, hipStream_t st) {
 
 template <int KS, int S>
 int launch_ck(const ConvArgs& a, int ck, int cout_tile, hipStream_t st) {
+  static_assert(S == 2, "the v1 kernel is kept for the stride-2 gather only");
   switch (ck) {
-    case 128:
-      if constexpr (S == 1) return launch_ct<KS, S, 128>(a, cout_tile, st);
-      return -1;
     case 64: return launch_ct<KS, S, 64>(a, cout_tile, st);
     default: return launch_ct<KS, S, 32>(a, cout_tile, st);
   }
@@ -414,7 +752,7 @@ extern "C" int pti_conv_pack_weights(const float* const* w, int nsrc, void* pack
   p.ks = ksize;
   p.flip = transpose_flip;
   p.cout_tile = pick_cout_tile(p.cout_l);
-  p.ck = pick_ck(p.cin_l, mode == PTI_CONV_S2PAD);
+  p.ck = (mode == PTI_CONV_S2PAD) ? pick_ck(p.cin_l, true) : pick_ck2(p.cin_l, p.cout_tile);
   p.total = (long long)p.cout_l * p.cin_l * ksize * ksize;
   const int blocks = (int)((p.total + 255) / 256);
   hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, p);
@@ -462,11 +800,14 @@ extern "C" int pti_conv2d_mfma(const void* x, const void* w_packed, const float*
   a.inv_cnt = d->prologue != PTI_PRO_NONE ? 1.0f / ((float)(d->cin / d->groups) * (float)d->h * (float)d->w) : 0.f;
   a.tiles_x = cdiv(d->wo, TW); a.tiles_y = cdiv(d->ho, TH);
   const int cout_tile = pick_cout_tile(d->cout);
-  const int ck = pick_ck(d->cin, d->mode == PTI_CONV_S2PAD);
-  int rc;
-  if (d->ksize == 1) rc = launch_ck<1, 1>(a, ck, cout_tile, (hipStream_t)s);
-  else if (d->mode == PTI_CONV_S2PAD) rc = launch_ck<3, 2>(a, ck, cout_tile, (hipStream_t)s);
-  else rc = launch_ck<3, 1>(a, ck, cout_tile, (hipStream_t)s);
+  int rc, ck;
+  if (d->mode == PTI_CONV_S2PAD) {
+    ck = pick_ck(d->cin, true);
+    rc = launch_ck<3, 2>(a, ck, cout_tile, (hipStream_t)s);
+  } else {
+    ck = pick_ck2(d->cin, cout_tile);
+    rc = d->ksize == 1 ? launch2<1>(a, ck, cout_tile, (hipStream_t)s) : launch2<3>(a, ck, cout_tile, (hipStream_t)s);
+  }
   if (rc != 0) PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: no kernel for ck=%d cout_tile=%d", ck, cout_tile);
   PTI_CHECK_LAUNCH("conv2d_mfma");
   return PTI_OK;

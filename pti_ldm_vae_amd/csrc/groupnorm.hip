@@ -187,8 +187,8 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnbArgs a) {
     const float v1 = sm[2 * i], v2 = sm[2 * i + 1];
     atomicAdd(&a.sums[((size_t)n * a.C + i) * 2], v1);
     atomicAdd(&a.sums[((size_t)n * a.C + i) * 2 + 1], v2);
-    if (a.dbeta) atomicAdd(&a.dbeta[i], v1);
-    if (a.dgamma) atomicAdd(&a.dgamma[i], v2);
+    // dgamma / dbeta are folded from sums[n][c] by block 0 of each sample in the apply kernel: adding them
+    // here would make every block of the launch hammer the same 2*C addresses
   }
 }
 
@@ -214,6 +214,12 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnbArgs a) {
     }
     c1[j] = t1 * a.inv_cnt;
     c2[j] = t2 * a.inv_cnt;
+  }
+  if (blockIdx.x == 0) {  // per-sample contribution to the affine gradients: N adds per address in total
+    for (int i = tid; i < a.C; i += 256) {
+      if (a.dbeta) atomicAdd(&a.dbeta[i], a.sums[((size_t)n * a.C + i) * 2]);
+      if (a.dgamma) atomicAdd(&a.dgamma[i], a.sums[((size_t)n * a.C + i) * 2 + 1]);
+    }
   }
   const int p0 = blockIdx.x * a.ppb, p1 = min(p0 + a.ppb, a.HW);
   const size_t base = (size_t)n * a.HW * a.C + lc * 8;
