@@ -297,6 +297,7 @@ class Engine:
         self.mfma_convs = [c for l in self.enc_layers + self.dec_layers for c in l.convs]
         self.direct_convs = [self.enc_in, self.enc_out, self.dec_in, self.dec_out]
         self.Lc = net.latent_channels
+        self._plist = list(net._param_by_name.values())
 
     def _make_layer(self, blk, prefix):
         if isinstance(blk, M.AEKLResBlock):
@@ -330,15 +331,17 @@ class Engine:
         self._zpool = None
 
     def refresh_weights(self):
-        """Re-derive the bf16 MFMA-packed / transposed operands when the fp32 masters changed."""
-        v = self.net.param_arena._version
+        """Re-derive the bf16 MFMA-packed / transposed operands when the fp32 masters changed.  In-place
+        updates through the nn.Parameters (torch optimisers, load_state_dict) bump the parameters' own
+        version counters; kernels that write the arena directly call ``net.mark_weights_dirty()``."""
+        v = sum(p._version for p in self._plist)
         if v == self.packed_version:
             return
         for c in self.mfma_convs:
             c.repack()
         for c in self.direct_convs:
             c.repack()
-        self.packed_version = self.net.param_arena._version
+        self.packed_version = v
 
     def _qp(self, name):
         L = self.Lc

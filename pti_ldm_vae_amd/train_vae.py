@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""VAE training driver for MI355X — the counterpart of the reference's ``vae_scripts/train_vae.py``.
+
+Same CLI (``-c/--config-file -g/--gpus --batch-size --lr --max-epochs --num-workers --cache-rate --seed
+--subset-size``), same JSON config keys, same run-directory layout and checkpoint
+files/keys (``trained_weights/autoencoder_last.pt``, ``autoencoder_epoch{E}.pth``, ``checkpoint_epoch{E}.pth``
+with ``epoch / autoencoder_state_dict / discriminator_state_dict / optimizer_g_state_dict /
+optimizer_d_state_dict / best_val_loss / total_step`` — train_vae.py:675-769), same data-parallel contract
+(one process per GPU under ``torchrun``, ``env://`` rendezvous, lr x world size, rank-0 checkpoints,
+rank-local validation means, best checkpoint chosen on rank 0's recon loss).
+
+What is different, on purpose:
+  * the step runs on the HIP engine through ``VAETrainer`` (no autograd tape, no DDP wrapper, no
+    unused-parameter search, no ``detect_anomaly``; ``--detect-anomaly`` is not needed without a tape);
+  * the perceptual (LPIPS) and adversarial terms are NOT available here (they need packages/weights that are
+    not installable offline): ``perceptual_weight`` and ``adv_enabled`` are read and reported, and must be
+    0/false — or pass ``--ignore-unavailable-terms`` to train with recon+KL(+AR is drop-in only) and a warning;
+  * data: the TIFF pipeline (``src/pti_ldm_vae/data``) is out of scope for this round;
+    ``--synthetic N`` trains on N seeded synthetic images of the configured patch size (z-scored elliptical
+    foreground, zero background), sharded across ranks like ``DistributedSampler``;
+  * logging goes to ``<run_dir>/metrics.jsonl`` with the reference's W&B metric names
+    (``train/recon_loss`` ... ``val/loss_total``), one host sync per ``--log-every`` steps.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+from .models import VAEModel, compute_total_loss
+from .trainer import VAETrainer
+from .utils import read_config, resolve_ar_settings
+from .utils.distributed import setup_ddp
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description="VAE training on MI355X (HIP engine)")
+    p.add_argument("-c", "--config-file", default="./config/vae_dente_no_adv.json")
+    p.add_argument("-g", "--gpus", default=1, type=int)
+    p.add_argument("--batch-size", type=int)
+    p.add_argument("--lr", type=float)
+    p.add_argument("--max-epochs", type=int)
+    p.add_argument("--num-workers", type=int, default=4)
+    p.add_argument("--cache-rate", type=float, default=0.0)
+    p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--subset-size", type=int)
+    p.add_argument("--synthetic", type=int, default=0, help="train on N synthetic images (no file I/O)")
+    p.add_argument("--log-every", type=int, default=20)
+    p.add_argument("--ignore-unavailable-terms", action="store_true")
+    p.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
+    return p.parse_args(argv)
+
+
+def setup_environment(args):
+    """train_vae.py:72-97 without the CUDA-isms that do not apply (cudnn.benchmark, detect_anomaly)."""
+    ddp = args.gpus > 1
+    if ddp:
+        rank, world = int(os.environ["LOCAL_RANK"]), int(os.environ["WORLD_SIZE"])
+        dist, device = setup_ddp(rank, world, backend=args.backend)
+    else:
+        rank, world, dist = 0, 1, None
+        device = torch.device("cuda:0")
+    if not torch.cuda.is_available():
+        raise RuntimeError("train_vae: the HIP engine needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(device if device.type == "cuda" else 0)
+    torch.set_num_threads(4)
+    return ddp, rank, world, torch.device(f"cuda:{rank}" if ddp else "cuda:0"), dist
+
+
+def load_config(args):
+    """train_vae.py:100-124: config keys become attributes; CLI overrides batch_size / max_epochs / lr."""
+    for k, v in read_config(args.config_file).items():
+        setattr(args, k, v)
+    if args.batch_size:
+        args.autoencoder_train["batch_size"] = args.batch_size
+    if args.max_epochs:
+        args.autoencoder_train["max_epochs"] = args.max_epochs
+    if args.lr:
+        args.autoencoder_train["lr"] = args.lr
+    args.model_dir = os.path.join(args.run_dir, "trained_weights")
+    return args
+
+
+class SyntheticShards:
+    """N seeded synthetic images, split train/val by ``train_split`` and sharded over ranks the way
+    ``DistributedSampler(shuffle=True, seed)`` does (every world-th index of a seed+epoch permutation,
+    wrapped to equal length).  Images are generated on the device, batch by batch."""
+
+    def __init__(self, n, channels, size, batch, rank, world, seed, device, train_split=0.9):
+        self.n_train = max(1, int(n * train_split))
+        self.n_val = max(1, n - self.n_train)
+        self.c, self.size, self.batch, self.rank, self.world, self.seed, self.dev = channels, size, batch, rank, world, seed, device
+        lin = torch.linspace(-1, 1, size[0], device=device)[:, None], torch.linspace(-1, 1, size[1], device=device)[None, :]
+        self.mask = ((lin[1] / 0.80) ** 2 + (lin[0] / 0.64) ** 2 <= 1.0).float()
+
+    def _image(self, idx):
+        g = torch.Generator(device=self.dev).manual_seed(self.seed * 1_000_003 + int(idx))
+        return torch.randn(self.c, *self.size, generator=g, device=self.dev) * self.mask
+
+    def _indices(self, n, epoch, offset):
+        g = torch.Generator().manual_seed(self.seed + epoch)
+        perm = torch.randperm(n, generator=g).tolist()
+        total = -(-n // self.world) * self.world
+        perm += perm[: total - n]
+        return [offset + i for i in perm[self.rank:total:self.world]]
+
+    def batches(self, epoch, train=True):
+        idx = self._indices(self.n_train, epoch, 0) if train else self._indices(self.n_val, 0, self.n_train)
+        for i in range(0, len(idx), self.batch):
+            yield torch.stack([self._image(j) for j in idx[i:i + self.batch]])
+
+
+def save_checkpoints(args, model, opt, epoch, val_loss, best_val_loss, best_epoch_saved, total_step, rank):
+    """train_vae.py:675-769: always ``autoencoder_last.pt``; on improvement replace the best files."""
+    if rank != 0:
+        return best_val_loss, best_epoch_saved
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    torch.save(sd, os.path.join(args.model_dir, "autoencoder_last.pt"))
+    if val_loss >= best_val_loss:
+        return best_val_loss, best_epoch_saved
+    if best_epoch_saved is not None:
+        for f in (f"checkpoint_epoch{best_epoch_saved}.pth", f"autoencoder_epoch{best_epoch_saved}.pth"):
+            f = os.path.join(args.model_dir, f)
+            if os.path.exists(f):
+                os.remove(f)
+    torch.save(sd, os.path.join(args.model_dir, f"autoencoder_epoch{epoch}.pth"))
+    osd = opt.state_dict()
+    for st in osd["state"].values():
+        st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"].cpu(), st["exp_avg_sq"].cpu()
+    torch.save({"epoch": epoch, "autoencoder_state_dict": sd, "discriminator_state_dict": None,
+                "optimizer_g_state_dict": osd, "optimizer_d_state_dict": None, "best_val_loss": val_loss,
+                "total_step": total_step}, os.path.join(args.model_dir, f"checkpoint_epoch{epoch}.pth"))
+    print(f"Best models saved for epoch {epoch}")
+    return val_loss, epoch
+
+
+def load_checkpoint(args, model, opt, device):
+    """train_vae.py:309-339 (with map_location fixed, Appendix D); ``checkpoint_dir`` is a FILE path."""
+    if not args.resume_ckpt:
+        print("[INFO] Training from scratch")
+        return 0, 100.0, 0, None
+    path = args.checkpoint_dir
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"[ERROR] Checkpoint not found: {path}")
+    ck = torch.load(path, map_location=device, weights_only=True)
+    model.load_state_dict(ck["autoencoder_state_dict"])
+    opt.load_state_dict(ck["optimizer_g_state_dict"])
+    print(f"[INFO] Resuming from epoch {ck['epoch'] + 1} | best_val_loss = {ck['best_val_loss']:.4f}")
+    return ck["epoch"] + 1, ck["best_val_loss"], ck["total_step"], ck["epoch"]
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    ddp, rank, world, device, dist = setup_environment(args)
+    args = load_config(args)
+    tr = args.autoencoder_train
+    ar_enabled, ar_gamma, _, _ = resolve_ar_settings(tr, getattr(args, "regularized_attributes", {}))
+    adv_enabled = bool(tr.get("adv_enabled", True))
+    unavailable = []
+    if float(tr.get("perceptual_weight", 0.0)) != 0.0:
+        unavailable.append(f"perceptual_weight={tr['perceptual_weight']} (LPIPS needs lpips+torchvision+weights)")
+    if adv_enabled:
+        unavailable.append("adv_enabled=true (PatchDiscriminator branch, active after epoch 5)")
+    if ar_enabled:
+        unavailable.append("AR-VAE loss (needs attribute files; available through the drop-in autograd path)")
+    if unavailable:
+        msg = "terms not available in the native trainer: " + "; ".join(unavailable)
+        if not args.ignore_unavailable_terms:
+            raise SystemExit(msg + " — set them to 0/false or pass --ignore-unavailable-terms")
+        if rank == 0:
+            print("[WARN] " + msg + " — training with recon + kl_weight*KL only")
+    if rank == 0:
+        run_dir = Path(args.run_dir)
+        if run_dir.exists() and not args.resume_ckpt:
+            raise ValueError(f"Run directory already exists: {run_dir}\nTo prevent overwriting previous runs:\n"
+                             "  1. Change 'run_dir' in your config file, or\n  2. Set 'resume_ckpt: true' to continue training")
+        Path(args.model_dir).mkdir(parents=True, exist_ok=True)
+        (run_dir / "splits").mkdir(parents=True, exist_ok=True)
+    if not args.synthetic:
+        raise SystemExit("train_vae: the TIFF data pipeline is out of scope this round (SURVEY.md §8f N1); "
+                         "run with --synthetic N")
+    torch.manual_seed(args.seed)                    # set_determinism(args.seed)
+    model = VAEModel.from_config(args.autoencoder_def).to(device)
+    if rank == 0:
+        print("\n=== Autoencoder model summary ===\n", model, "\n=================================\n")
+    pg = None
+    trainer = VAETrainer(model, lr=tr["lr"], world_size=world, process_group=pg, recon_loss=tr.get("recon_loss", "l1"),
+                         kl_weight=tr["kl_weight"], rank_eps_offset=rank)
+    start_epoch, best_val, total_step, best_epoch_saved = load_checkpoint(args, model, trainer.opt, device)
+    model.autoencoder.mark_weights_dirty()
+    n = args.subset_size or args.synthetic
+    data = SyntheticShards(n, args.autoencoder_def["in_channels"], tuple(tr["patch_size"]), tr["batch_size"], rank, world,
+                           args.seed, device, args.train_split)
+    if rank == 0:
+        with open(Path(args.run_dir) / "splits" / "vae_split.json", "w", encoding="utf-8") as f:
+            json.dump({"seed": args.seed, "train_split": args.train_split, "subset_size": args.subset_size,
+                       "val_dir": args.val_dir, "train_files": [f"synthetic:{i}" for i in range(data.n_train)],
+                       "val_files": [f"synthetic:{i}" for i in range(data.n_train, data.n_train + data.n_val)]}, f, indent=2)
+    log = open(Path(args.run_dir) / "metrics.jsonl", "a") if rank == 0 else None
+    kl_w, max_epochs, val_interval = tr["kl_weight"], tr["max_epochs"], tr["val_interval"]
+    for epoch in range(start_epoch, max_epochs):
+        t0 = time.time()
+        seen = 0
+        for step, images in enumerate(data.batches(epoch, train=True)):
+            out = trainer.step(images)
+            total_step += 1
+            seen += images.shape[0]
+            if log is not None and step % args.log_every == 0:
+                log.write(json.dumps({"train/step": total_step, "train/recon_loss": out["recon"].item(),
+                                      "train/kl_loss": out["kl"].item(), "train/loss_total": out["loss"].item(),
+                                      "train/perceptual_loss": 0.0, "train/adv_gen_loss": 0.0,
+                                      "train/adv_disc_loss": 0.0}) + "\n")
+                log.flush()
+        if epoch % val_interval == 0:
+            rsum = ksum = torch.zeros((), device=device)
+            nb = 0
+            for images in data.batches(epoch, train=False):
+                v, _ = trainer.eval_losses(images)
+                rsum, ksum, nb = rsum + v["recon"], ksum + v["kl"], nb + 1
+            val_recon, val_kl = (rsum / max(nb, 1)).item(), (ksum / max(nb, 1)).item()
+            val_total = compute_total_loss(val_recon, val_kl, 0.0, 0.0, 0.0, kl_weight=kl_w, perceptual_weight=0.0,
+                                           adv_weight=0.0, ar_gamma=ar_gamma, ar_vae_enabled=False)
+            torch.cuda.synchronize()
+            dt = time.time() - t0
+            if rank == 0:
+                print(f"Epoch {epoch} val_loss: {val_recon:.4f} | Time: {dt:.1f}s | {seen * world / dt:.1f} img/s")
+                log.write(json.dumps({"epoch": epoch, "val/recon_loss": val_recon, "val/kl_loss": val_kl,
+                                      "val/loss_total": val_total, "val/perceptual_loss": 0.0, "time_per_epoch": dt}) + "\n")
+                log.flush()
+            best_val, best_epoch_saved = save_checkpoints(args, model, trainer.opt, epoch, val_recon, best_val,
+                                                          best_epoch_saved, total_step, rank)
+    if log is not None:
+        log.close()
+    if ddp:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
