@@ -75,6 +75,16 @@ int64_t pti_conv_packed_bytes(int cout, int cin, int ksize, int mode);
 int pti_conv_pack_weights(const float* const* w_oihw, int nsrc, void* packed, int cout, int cin,
                           int ksize, int mode, int transpose_flip, pti_stream_t s);
 
+/* Batched form (one launch for all layers of the model after an optimiser step): the caller keeps a
+ * table of pti_conv_pack_entry_bytes()-byte entries; pti_conv_pack_table_fill writes ONE entry into HOST
+ * memory and returns its size in 256-element blocks; the caller uploads the table plus the running
+ * first-block index of every entry, then launches everything with pti_conv_pack_weights_batched.   */
+int pti_conv_pack_entry_bytes(void);
+int pti_conv_pack_table_fill(void* host_entry, const float* w_oihw_dev, void* packed_dev, int cout,
+                             int cin, int ksize, int mode, int transpose_flip, int64_t* nblocks);
+int pti_conv_pack_weights_batched(const void* table_dev, const int* blk_first_dev, int n,
+                                  int total_blocks, pti_stream_t s);
+
 /* ---- GroupNorm statistics (nn.GroupNorm's reduction) ---------------------------------- */
 /* stats[n][g] += {sum, sumsq} of x[n, :, channels of g]; stats must be zeroed by the caller. */
 int pti_gn_stats(const void* x_nhwc_bf16, float* stats, int n, int hw, int c, int groups,
@@ -99,13 +109,14 @@ int pti_conv2d_direct(const void* x, const float* w_tck, const float* bias, cons
  * dw[tap*st_tap + cw*st_cw + k*st_k] += sum_p narrow[p][k] * P(wide)[p + sgn*(tap offset)][cw]
  * for every narrow channel k < cn; wide is dense NHWC bf16 with cw channels (prologue P optional),
  * narrow is fp32/bf16 with element strides narrow_stride[n,h,w,c].  dbias_wide[cw] += column sums
- * of wide, dbias_narrow[k] += sum of narrow (either may be NULL).  Accumulates with atomics.    */
+ * of wide, dbias_narrow[k] += sum of narrow (either may be NULL).  Per-block partials go to `workspace`
+ * (plain stores) and are summed in block order by a second launch: deterministic, += into the outputs.  */
 int pti_wgrad_direct(const void* wide, const void* narrow, float* dw, float* dbias_wide,
                      float* dbias_narrow, const float* in_stats, const float* gamma,
                      const float* beta, int n, int h, int w, int cw, int cn, int ksize, int sgn,
                      int prologue, int groups, float eps, int narrow_f32,
                      const int64_t* narrow_stride, int64_t dw_stride_tap, int64_t dw_stride_cw,
-                     int64_t dw_stride_k, pti_stream_t s);
+                     int64_t dw_stride_k, void* workspace, int64_t workspace_bytes, pti_stream_t s);
 
 /* ---- convolution weight gradient (autograd of nn.Conv2d, MFMA path) ----------------------- */
 int64_t pti_conv_wgrad_workspace_bytes(int cout, int cin, int ksize, int splits);

@@ -40,11 +40,14 @@ SIGNATURES = {
     "pti_last_error_string": (C.c_char_p, []),
     "pti_conv_packed_bytes": (_I64, [_I, _I, _I, _I]),
     "pti_conv_pack_weights": (_I, [C.POINTER(_P), _I, _P, _I, _I, _I, _I, _I, _P]),
+    "pti_conv_pack_entry_bytes": (_I, []),
+    "pti_conv_pack_table_fill": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, C.POINTER(_I64)]),
+    "pti_conv_pack_weights_batched": (_I, [_P, _P, _I, _I, _P]),
     "pti_gn_stats": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "pti_conv2d_mfma": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(ConvDesc), _P]),
     "pti_conv2d_direct": (_I, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(ConvDesc), _P]),
     "pti_wgrad_direct": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I,
-                              C.POINTER(_I64), _I64, _I64, _I64, _P]),
+                              C.POINTER(_I64), _I64, _I64, _I64, _P, _I64, _P]),
     "pti_conv_wgrad_workspace_bytes": (_I64, [_I, _I, _I, _I]),
     "pti_conv_wgrad_mfma": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I, C.POINTER(ConvDesc), _P]),
     "pti_gn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),

@@ -176,6 +176,7 @@ struct WGArgs {
   float* dw;          // fp32 OIHW gradient
   float* dbias_wide;  // optional [CW]: column sums of wide   (FEWCIN layer bias grad)
   float* dbias_narrow;// optional [narrow ch]: sum of narrow   (FEWCOUT layer bias grad)
+  float* part;        // workspace: [cn][blocks][80*NC + 1] per-block partial sums (plain stores)
   const float* in_stats; const float* gamma; const float* beta;
   int N, H, W, CW, KS, sgn;
   int prologue, groups; float eps, inv_cnt;
@@ -273,21 +274,49 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(WGArgs a) {
     if (lane < NC) red[(wave * 80 + 72 + j) * NC + lane] = v;
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < 80 * NC; e += 256) {
-    const int vi = e / NC, c = e % NC;
-    const float v = red[e] + red[80 * NC + e] + red[2 * 80 * NC + e] + red[3 * 80 * NC + e];
-    if (vi < 72) {
-      const int t = vi / 8, j = vi % 8;
-      if (t < ntap) atomicAdd(&a.dw[t * a.dw_stride_tap + (c * 8 + j) * a.dw_stride_cw + k * a.dw_stride_k], v);
-    } else if (a.dbias_wide && k == 0) {
-      atomicAdd(&a.dbias_wide[c * 8 + (vi - 72)], v);
-    }
-  }
-  if (a.dbias_narrow) {
-    // every NC-th lane carries a distinct pixel's narrow value: count each pixel once (lc == 0)
+  // per-block partials with plain stores; wgrad_direct_finalize sums them in block order (deterministic, and
+  // no thousands of atomics on the same few hundred addresses)
+  float* mine = a.part + ((size_t)k * gridDim.x + blockIdx.x) * (80 * NC + 1);
+  for (int e = threadIdx.x; e < 80 * NC; e += 256)
+    mine[e] = red[e] + red[80 * NC + e] + red[2 * 80 * NC + e] + red[3 * 80 * NC + e];
+  {
     float v = (lc == 0) ? nsum : 0.f;
     v = wave_sum(v);
-    if (lane == 0) atomicAdd(&a.dbias_narrow[k], v);
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) mine[80 * NC] = red[0] + red[1] + red[2] + red[3];
+  }
+}
+
+// out(+=) sum over blocks of the partials written by wgrad_direct_kernel
+__global__ __launch_bounds__(256) void wgrad_direct_finalize_kernel(WGArgs a, int nblocks) {
+  const int NC = a.CW / 8, k = blockIdx.y;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int per = 80 * NC + 1;
+  if (e >= per) return;
+  const float* base = a.part + (size_t)k * nblocks * per + e;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = 0;
+  for (; b + 3 < nblocks; b += 4) {
+    s0 += base[(size_t)b * per];
+    s1 += base[(size_t)(b + 1) * per];
+    s2 += base[(size_t)(b + 2) * per];
+    s3 += base[(size_t)(b + 3) * per];
+  }
+  for (; b < nblocks; ++b) s0 += base[(size_t)b * per];
+  const float v = (s0 + s1) + (s2 + s3);
+  const int ntap = a.KS * a.KS;
+  if (e == 80 * NC) {
+    if (a.dbias_narrow) a.dbias_narrow[k] += v;
+    return;
+  }
+  const int vi = e / NC, c = e % NC;
+  if (vi < 72) {
+    const int t = vi / 8, j = vi % 8;
+    if (t < ntap) a.dw[t * a.dw_stride_tap + (c * 8 + j) * a.dw_stride_cw + k * a.dw_stride_k] += v;
+  } else if (a.dbias_wide && k == 0) {
+    a.dbias_wide[c * 8 + (vi - 72)] += v;
   }
 }
 
@@ -340,8 +369,9 @@ extern "C" int pti_wgrad_direct(const void* wide, const void* narrow, float* dw,
                                 float* dbias_narrow, const float* in_stats, const float* gamma, const float* beta,
                                 int n, int h, int w, int cw, int cn, int ksize, int sgn, int prologue, int groups,
                                 float eps, int narrow_f32, const int64_t* narrow_stride, int64_t dw_stride_tap,
-                                int64_t dw_stride_cw, int64_t dw_stride_k, pti_stream_t s) {
-  if (!wide || !narrow || !dw || !narrow_stride) PTI_FAIL(PTI_EINVAL, "wgrad_direct: null pointer");
+                                int64_t dw_stride_cw, int64_t dw_stride_k, void* workspace, int64_t workspace_bytes,
+                                pti_stream_t s) {
+  if (!wide || !narrow || !dw || !narrow_stride || !workspace) PTI_FAIL(PTI_EINVAL, "wgrad_direct: null pointer");
   if (cw % 8 || cw < 8 || cw > 256 || (cw & (cw - 1)) || cn <= 0 || (ksize != 1 && ksize != 3))
     PTI_FAIL(PTI_EUNSUPPORTED, "wgrad_direct: cw=%d cn=%d k=%d", cw, cn, ksize);
   if (prologue && (!in_stats || !gamma || !beta || groups <= 0 || cw % groups)) PTI_FAIL(PTI_EINVAL, "wgrad_direct: prologue args");
@@ -357,9 +387,16 @@ extern "C" int pti_wgrad_direct(const void* wide, const void* narrow, float* dw,
   const long long npix = (long long)n * h * w;
   const int ppb = 256 / (cw / 8);
   long long blocks = (npix + ppb - 1) / ppb;
-  if (blocks > 512) blocks = 512;
+  if (blocks > 2048) blocks = 2048;
+  const long long per = 80 * (cw / 8) + 1;
+  while (blocks > 1 && blocks * cn * per * 4 > workspace_bytes) blocks /= 2;
+  if (blocks * cn * per * 4 > workspace_bytes) PTI_FAIL(PTI_EINVAL, "wgrad_direct: workspace too small");
+  a.part = (float*)workspace;
   hipLaunchKernelGGL(wgrad_direct_kernel, dim3((unsigned)blocks, cn), dim3(256), 4 * 80 * (cw / 8) * sizeof(float),
                      (hipStream_t)s, a);
+  PTI_CHECK_LAUNCH("wgrad_direct");
+  hipLaunchKernelGGL(wgrad_direct_finalize_kernel, dim3((unsigned)((per + 255) / 256), cn), dim3(256), 0, (hipStream_t)s, a,
+                     (int)blocks);
   PTI_CHECK_LAUNCH("wgrad_direct");
   return PTI_OK;
 }

@@ -677,9 +677,7 @@ struct PackArgs {
   long long total;
 };
 
-__global__ void pack_weights_kernel(PackArgs p) {
-  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= p.total) return;
+__device__ __forceinline__ void pack_one(const PackArgs& p, long long e) {
   const int NT = p.cout_tile / 32, KPC = p.ck / 16, KBC = p.ks * p.ks * KPC, nch = p.cin_l / p.ck;
   long long r = e;
   const int j = r % 8; r /= 8;
@@ -700,6 +698,24 @@ __global__ void pack_weights_kernel(PackArgs p) {
     v = p.src[0][((size_t)ci * p.cin_o + co) * kk + (kk - 1 - tap)];
   }
   p.dst[e] = (bf16)v;
+}
+
+__global__ void pack_weights_kernel(PackArgs p) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < p.total) pack_one(p, e);
+}
+
+// batched form: table[i] describes one weight, blk_first[i] its first block; blocks are 256 elements
+__global__ void pack_weights_batched_kernel(const PackArgs* __restrict__ table, const int* __restrict__ blk_first, int n) {
+  int lo = 0, hi = n - 1;
+  const int b = blockIdx.x;
+  while (lo < hi) {  // last entry with blk_first <= b
+    const int mid = (lo + hi + 1) >> 1;
+    if (blk_first[mid] <= b) lo = mid; else hi = mid - 1;
+  }
+  const PackArgs p = table[lo];
+  const long long e = (long long)(b - blk_first[lo]) * 256 + threadIdx.x;
+  if (e < p.total) pack_one(p, e);
 }
 
 template <int KS, int S, int CK, int COUT_TILE>
@@ -757,6 +773,45 @@ extern "C" int pti_conv_pack_weights(const float* const* w, int nsrc, void* pack
   const int blocks = (int)((p.total + 255) / 256);
   hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, p);
   PTI_CHECK_LAUNCH("pack_weights");
+  return PTI_OK;
+}
+
+static int fill_pack(PackArgs& p, const float* w, void* packed, int cout, int cin, int ksize, int mode, int flip) {
+  if (cout % 32 || cin % 32 || (ksize != 1 && ksize != 3)) return -1;
+  for (int i = 0; i < 4; ++i) p.src[i] = nullptr;
+  p.src[0] = w;
+  p.nsrc = 1;
+  p.dst = (bf16*)packed;
+  p.cout_o = cout; p.cin_o = cin;
+  p.cout_l = flip ? cin : cout;
+  p.cin_l = flip ? cout : cin;
+  p.ks = ksize; p.flip = flip;
+  p.cout_tile = pick_cout_tile(p.cout_l);
+  p.ck = (mode == PTI_CONV_S2PAD) ? pick_ck(p.cin_l, true) : pick_ck2(p.cin_l, p.cout_tile);
+  p.total = (long long)p.cout_l * p.cin_l * ksize * ksize;
+  return 0;
+}
+
+// Host-side table builder + single launch: entries i = 0..n-1 (w[i] fp32 [cout,cin,k,k] contiguous, possibly a
+// fused [3C,C] view).  table_dev / blk_dev: device scratch of n*sizeof(pti_pack_entry_t) (96 B) / n*4 bytes
+// that the CALLER filled through pti_conv_pack_table_fill (host) + its own H2D copy.
+extern "C" int pti_conv_pack_entry_bytes(void) { return (int)sizeof(PackArgs); }
+extern "C" int pti_conv_pack_table_fill(void* host_entry, const float* w, void* packed, int cout, int cin, int ksize,
+                                        int mode, int transpose_flip, int64_t* nblocks) {
+  if (!host_entry || !w || !packed || !nblocks) PTI_FAIL(PTI_EINVAL, "pack_table_fill: null pointer");
+  PackArgs p;
+  if (fill_pack(p, w, packed, cout, cin, ksize, mode, transpose_flip))
+    PTI_FAIL(PTI_EUNSUPPORTED, "pack_table_fill: cout=%d cin=%d k=%d", cout, cin, ksize);
+  *(PackArgs*)host_entry = p;
+  *nblocks = (p.total + 255) / 256;
+  return PTI_OK;
+}
+extern "C" int pti_conv_pack_weights_batched(const void* table_dev, const int* blk_first_dev, int n, int total_blocks,
+                                             pti_stream_t s) {
+  if (!table_dev || !blk_first_dev || n <= 0 || total_blocks <= 0) PTI_FAIL(PTI_EINVAL, "pack_weights_batched: bad args");
+  hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)s,
+                     (const PackArgs*)table_dev, blk_first_dev, n);
+  PTI_CHECK_LAUNCH("pack_weights_batched");
   return PTI_OK;
 }
 

@@ -257,23 +257,44 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgArgs a) {
 }
 
 // dW[co][ci][tap] (=|+=) sum_s slab[s][tap][co][ci];  dbias[co] (=|+=) sum_s slab[s][KK*Cout*Cin + co]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, long long stride, int S, float* __restrict__ dw,
-                                    float* __restrict__ dbias, int Cout, int Cin, int KK, int accumulate) {
-  const long long total = (long long)KK * Cout * Cin;
-  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < total) {
-    float s = 0.f;
-    for (int k = 0; k < S; ++k) s += slab[(size_t)k * stride + e];
-    const int ci = e % Cin;
-    const int co = (e / Cin) % Cout;
-    const int t = e / ((long long)Cin * Cout);
-    const size_t o = ((size_t)co * Cin + ci) * KK + t;
-    dw[o] = accumulate ? dw[o] + s : s;
-  } else if (dbias && e < total + Cout) {
-    float s = 0.f;
-    for (int k = 0; k < S; ++k) s += slab[(size_t)k * stride + e];
-    const int co = (int)(e - total);
-    dbias[co] = accumulate ? dbias[co] + s : s;
+// block = 16 float4 columns (64 consecutive slab elements) x 16 slab groups: slabs are summed by 16 threads in
+// parallel (fixed order => deterministic), folded through LDS, and written by the first group.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, long long stride, int S,
+                                                           float* __restrict__ dw, float* __restrict__ dbias, int Cout,
+                                                           int Cin, int KK, int accumulate) {
+  __shared__ f32x4 red[16][16];
+  const long long total = (long long)KK * Cout * Cin;   // + Cout bias entries behind it; both multiples of 4
+  const int col = threadIdx.x & 15, sg = threadIdx.x >> 4;
+  const long long e = ((long long)blockIdx.x * 16 + col) * 4;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+  if (e < total + Cout) {
+    int k = sg;
+    for (; k + 16 < S; k += 32) {
+      s0 += *(const f32x4*)(slab + (size_t)k * stride + e);
+      s1 += *(const f32x4*)(slab + (size_t)(k + 16) * stride + e);
+    }
+    if (k < S) s0 += *(const f32x4*)(slab + (size_t)k * stride + e);
+  }
+  red[sg][col] = s0 + s1;
+  __syncthreads();
+  if (sg == 0 && e < total + Cout) {
+    f32x4 sum = red[0][col];
+#pragma unroll
+    for (int g = 1; g < 16; ++g) sum += red[g][col];
+    if (e < total) {
+      const int ci = e % Cin;
+      const int co = (e / Cin) % Cout;
+      const int t = e / ((long long)Cin * Cout);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const size_t o = ((size_t)co * Cin + ci + j) * KK + t;
+        dw[o] = accumulate ? dw[o] + sum[j] : sum[j];
+      }
+    } else if (dbias) {
+      const int co = (int)(e - total);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dbias[co + j] = accumulate ? dbias[co + j] + sum[j] : sum[j];
+    }
   }
 }
 
@@ -334,7 +355,7 @@ extern "C" int pti_conv_wgrad_mfma(const void* x, const void* dy, const float* i
   else launch_wt<3, 1>(a, co_t, ci_t, tiles_cc, st);
   PTI_CHECK_LAUNCH("conv_wgrad_mfma");
   const long long total = a.slab_stride;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)workspace,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total / 4 + 15) / 16)), dim3(256), 0, st, (const float*)workspace,
                      a.slab_stride, S, dw, dbias, d->cout, d->cin, kk, accumulate);
   PTI_CHECK_LAUNCH("conv_wgrad_reduce");
   return PTI_OK;

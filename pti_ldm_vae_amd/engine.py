@@ -270,6 +270,7 @@ class Engine:
         self.grad_ready_cb = None
         self._range_cache = {}
         self._zpool, self._zoff, self._zpool_size = None, 0, 1 << 16
+        self._packer = None
         ops.L.lib()  # fail loudly now if the HIP extension is missing
         for c in net.channels:
             if c % 32:
@@ -337,8 +338,15 @@ class Engine:
         v = sum(p._version for p in self._plist)
         if v == self.packed_version:
             return
-        for c in self.mfma_convs:
-            c.repack()
+        if self._packer is None:
+            entries = []
+            for c in self.mfma_convs:
+                dmode = PTI_CONV_ZINS if c.mode == PTI_CONV_S2PAD else PTI_CONV_S1
+                entries += [(c._w(), c.ksize, c.mode, False), (c._w(), c.ksize, dmode, True)]
+            self._packer = ops.BatchedPacker(entries, self.dev)
+            for i, c in enumerate(self.mfma_convs):
+                c.wp, c.wpt = self._packer.outputs[2 * i], self._packer.outputs[2 * i + 1]
+        self._packer.run()
         for c in self.direct_convs:
             c.repack()
         self.packed_version = v

@@ -169,16 +169,18 @@ def conv_direct(x, w_tck, bias, y, *, n, h, w, cin, cout, ksize=3, x_layout="nhw
 
 
 def wgrad_direct(wide, narrow, dw, *, n, h, w, cw, cn, ksize, sgn, narrow_layout, dw_strides, dbias_wide=None,
-                 dbias_narrow=None, prologue=PTI_PRO_NONE, in_stats=None, gamma=None, beta=None, groups=0, eps=1e-6):
+                 dbias_narrow=None, prologue=PTI_PRO_NONE, in_stats=None, gamma=None, beta=None, groups=0, eps=1e-6,
+                 workspace=None):
     """dw[tap,cw,k] += sum_p narrow[p,k] * T(wide)[p + sgn*tap, cw]; dw_strides = (tap, cw, k) element
     strides into the fp32 OIHW gradient ``dw`` (must be zero-initialised or hold a running sum)."""
     _chk(wide, BF16, "wide", 4)
     _chk(dw, F32, "dw")
     ns = (C.c_int64 * 4)(*_strides4(narrow, narrow_layout))
+    ws = workspace if workspace is not None else wgrad_workspace(wide.device)
     L.check(L.lib().pti_wgrad_direct(_ptr(wide), _ptr(narrow), _ptr(dw), _ptr(dbias_wide), _ptr(dbias_narrow),
                                      _ptr(in_stats), _ptr(gamma), _ptr(beta), n, h, w, cw, cn, ksize, sgn, prologue,
                                      groups, eps, int(narrow.dtype == F32), ns, dw_strides[0], dw_strides[1],
-                                     dw_strides[2], _stream()), "pti_wgrad_direct")
+                                     dw_strides[2], _ptr(ws), ws.numel() * 4, _stream()), "pti_wgrad_direct")
     return dw
 
 
@@ -355,3 +357,34 @@ def attention_bwd(qkv, o, dout, lse2, delta, dqkv):
     L.check(L.lib().pti_attention_bwd(_ptr(qkv), _ptr(o), _ptr(dout), _ptr(lse2), _ptr(delta), _ptr(dqkv), b, l, c,
                                       _stream()), "pti_attention_bwd")
     return dqkv
+
+
+class BatchedPacker:
+    """All MFMA weight packs of a model as ONE kernel launch (the per-layer form costs ~110 launches per
+    optimiser step).  Entries are (fp32 weight view [cout,cin,k,k], ksize, mode, flip); the packed outputs are
+    allocated here and live at fixed addresses, as do the weights (views of the parameter arena)."""
+
+    def __init__(self, entries, device):
+        lib = L.lib()
+        esz = lib.pti_conv_pack_entry_bytes()
+        host = bytearray(esz * len(entries))
+        hbuf = (C.c_char * len(host)).from_buffer(host)
+        first, total, self.outputs = [], 0, []
+        for i, (w, ksize, mode, flip) in enumerate(entries):
+            _chk(w, F32, "weight")
+            cout, cin = w.shape[0], w.shape[1]
+            out = torch.empty(w.numel(), dtype=BF16, device=device)
+            nb = C.c_int64(0)
+            L.check(lib.pti_conv_pack_table_fill(C.byref(hbuf, i * esz), _ptr(w), _ptr(out), cout, cin, ksize, mode,
+                                                 int(flip), C.byref(nb)), "pti_conv_pack_table_fill")
+            first.append(total)
+            total += nb.value
+            self.outputs.append(out)
+        self.n, self.total_blocks = len(entries), total
+        self.table = torch.frombuffer(host, dtype=torch.uint8).clone().to(device)
+        self.first = torch.tensor(first, dtype=torch.int32, device=device)
+        self._keep = [e[0] for e in entries]
+
+    def run(self):
+        L.check(L.lib().pti_conv_pack_weights_batched(_ptr(self.table), _ptr(self.first), self.n, self.total_blocks,
+                                                      _stream()), "pti_conv_pack_weights_batched")
