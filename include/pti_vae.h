@@ -134,6 +134,16 @@ int pti_conv_wgrad_mfma(const void* x, const void* dy, const float* in_stats, co
 int pti_gn_bwd(const void* x, const void* da, const void* dres, void* dx, const float* stats,
                const float* gamma, const float* beta, float* sums, float* dgamma, float* dbeta,
                int n, int hw, int c, int groups, float eps, int silu, pti_stream_t s);
+/* Fused form used by the engine: the data-gradient conv computes dy = dA * act'(GN(gx)) in its epilogue and
+ * accumulates gsums[n][c] = {sum dy, sum dy*xhat} (gx = the GroupNorm input, same shape as the conv output;
+ * d->groups / d->eps describe that GroupNorm; d is a plain stride-1 / zero-insert launch, w_packed the
+ * transposed+flipped pack).  pti_gn_bwd_apply then finishes dx = rstd*(gamma*dy - c1 - xhat*c2) [+ dres].    */
+int pti_conv2d_mfma_gnbwd(const void* dy_in, const void* w_packed, const void* gx, const float* gstats,
+                          const float* ggamma, const float* gbeta, void* dy_out, float* gsums,
+                          const pti_conv_desc* d, int silu, pti_stream_t s);
+int pti_gn_bwd_apply(const void* x, const void* dy, const void* dres, void* dx, const float* stats,
+                     const float* gamma, const float* beta, const float* sums, float* dgamma,
+                     float* dbeta, int n, int hw, int c, int groups, float eps, pti_stream_t s);
 /* y[n,h,w,c] = sum of the 2x2 block of x[n,2h,2w,c]: backward of nn.Upsample(nearest, 2x).     */
 int pti_pool2x2_sum(const void* x, void* y, int n, int h, int w, int c, pti_stream_t s);
 

@@ -22,7 +22,7 @@ struct DArgs {
   int N, H, W, Cin, Cout, KS;
   int prologue, groups;
   float eps, inv_cnt;
-  int in_f32, out_f32;
+  int in_f32, out_f32, w_lds;
   long long is[4], os[4];  // n,h,w,c element strides of the narrow tensor(s)
 };
 
@@ -81,6 +81,14 @@ __global__ __launch_bounds__(256) void direct_fewcout_kernel(DArgs a) {
   const int cpg = a.prologue ? a.Cin / a.groups : 1;
   const bf16* X = (const bf16*)a.x;
   // single-output-channel layers (decoder conv_out at full resolution) keep their 9x8 weights in registers
+  extern __shared__ float wsm[];   // [k*k][Cin][Cout] when it fits (dynamic LDS size > 0)
+  const int wcount = a.KS * a.KS * a.Cin * a.Cout;
+  const bool w_in_lds = (MAXCO != 1) && (a.w_lds != 0);
+  if (w_in_lds) {
+    for (int i = threadIdx.x; i < wcount; i += 256) wsm[i] = a.w[i];
+    __syncthreads();
+  }
+  const float* W = w_in_lds ? wsm : a.w;
   float wreg[MAXCO == 1 ? 9 : 1][8];
   if constexpr (MAXCO == 1) {
 #pragma unroll
@@ -139,7 +147,7 @@ __global__ __launch_bounds__(256) void direct_fewcout_kernel(DArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[0] += f[j] * wreg[t][j];
       } else {
-        const float* wt = a.w + ((size_t)(a.KS == 3 ? t : 0) * a.Cin + lc * 8) * a.Cout;
+        const float* wt = W + ((size_t)(a.KS == 3 ? t : 0) * a.Cin + lc * 8) * a.Cout;
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -328,7 +336,7 @@ static int fill_common(DArgs& a, const void* x, const float* w, const float* bia
   a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout; a.KS = d->ksize;
   a.prologue = d->prologue; a.groups = d->groups; a.eps = d->eps;
   a.inv_cnt = d->prologue ? 1.0f / ((float)(d->cin / d->groups) * (float)d->h * (float)d->w) : 0.f;
-  a.in_f32 = d->in_f32; a.out_f32 = d->out_f32;
+  a.in_f32 = d->in_f32; a.out_f32 = d->out_f32; a.w_lds = 0;
   for (int i = 0; i < 4; ++i) { a.is[i] = d->in_stride[i]; a.os[i] = d->out_stride[i]; }
   return 0;
 }
@@ -355,9 +363,13 @@ extern "C" int pti_conv2d_direct(const void* x, const float* w, const float* bia
     long long blocks = (npix + ppb - 1) / ppb;
     if (blocks > 65536) blocks = 65536;
     if (blocks > 2048) blocks = 2048;
+    const size_t wbytes = (size_t)d->ksize * d->ksize * d->cin * d->cout * sizeof(float);
+    const size_t lds = (d->cout > 1 && wbytes <= 60 * 1024) ? wbytes : 0;
+    a.w_lds = lds ? 1 : 0;
+    if (lds && blocks > 512) blocks = 512;   // amortise the weight staging over several pixels per block
     if (d->cout == 1) hipLaunchKernelGGL(direct_fewcout_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, a);
-    else if (d->cout <= 4) hipLaunchKernelGGL(direct_fewcout_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, a);
-    else hipLaunchKernelGGL(direct_fewcout_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, a);
+    else if (d->cout <= 4) hipLaunchKernelGGL(direct_fewcout_kernel<4>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)s, a);
+    else hipLaunchKernelGGL(direct_fewcout_kernel<16>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)s, a);
   } else {
     PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_direct: cin=%d cout=%d is not a degenerate-channel shape", d->cin, d->cout);
   }

@@ -71,6 +71,13 @@ struct ConvArgs {
   int mode, prologue, groups, out_groups;
   float eps, inv_cnt;
   int tiles_x, tiles_y;
+  // fused GroupNorm(+SiLU) backward reduction (data-gradient launches): res = GN input gx (same shape as y);
+  // y = dA * act'(GN(gx)) and g_sums[n][c] += {sum dy, sum dy*xhat}
+  int gn_mode;            // 0 off, 1 GN, 2 GN+SiLU
+  int g_groups;
+  float g_inv_cnt, g_eps;
+  const float* g_stats; const float* g_gamma; const float* g_beta;
+  float* g_sums;
 };
 
 template <int KS, int S, int CK, int COUT_TILE>
@@ -554,10 +561,75 @@ __global__ __launch_bounds__(256, 2) void conv_mfma2_kernel(ConvArgs a) {
     }
     __syncthreads();
   }
-  // (B) registers -> (+bias, +residual) -> bf16 -> LDS tile; statistics accumulate in-lane over the 4 fragments
+  const int col0 = wn * 32 + 4 * hsel;   // channel within the CT tile
   float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f};   // per quad q (or first pair when ocpg==2)
   float su1[4] = {0.f, 0.f, 0.f, 0.f}, su2[4] = {0.f, 0.f, 0.f, 0.f};   // second pair of the quad when ocpg==2
-  const int col0 = wn * 32 + 4 * hsel;   // channel within the CT tile
+  if (a.gn_mode) {
+    // (B') data gradient + GroupNorm backward reduction: etile holds the GN input gx
+    const int gcpg = a.Cout / a.g_groups;
+    float* gsm = reinterpret_cast<float*>(smem + C::STAT_OFF);   // [CT][2], zeroed before the main loop
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int col = col0 + 8 * q, ch0 = ct * CT + col;
+      float scv[4], shv[4], muv[4], rsv[4], l1[4] = {0.f, 0.f, 0.f, 0.f}, l2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int g = (ch0 + r) / gcpg;
+        const float sum = a.g_stats[(n * a.g_groups + g) * 2], sq = a.g_stats[(n * a.g_groups + g) * 2 + 1];
+        const float mean = sum * a.g_inv_cnt;
+        const float rstd = rsqrtf(fmaxf(sq * a.g_inv_cnt - mean * mean, 0.f) + a.g_eps);
+        muv[r] = mean; rsv[r] = rstd;
+        scv[r] = rstd * a.g_gamma[ch0 + r];
+        shv[r] = a.g_beta[ch0 + r] - mean * scv[r];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int p = (8 * wm + 2 * i + (j >> 4)) * 16 + (j & 15);
+        const bool inb = (oy0 + (p >> 4) < a.Ho) && (ox0 + (p & 15) < a.Wo);
+        unsigned char* ep = etile + p * C::EPITCH + col * 2;
+        const u32x2 rr = *(const u32x2*)ep;
+        float xv[4] = {__uint_as_float(rr[0] << 16), __uint_as_float(rr[0] & 0xffff0000u),
+                       __uint_as_float(rr[1] << 16), __uint_as_float(rr[1] & 0xffff0000u)};
+        float dv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[i][4 * q + r];
+          if (a.gn_mode == 2) v *= dsilu_f(xv[r] * scv[r] + shv[r]);
+          dv[r] = v;
+        }
+        const u32x2 packed = pack4(dv[0], dv[1], dv[2], dv[3]);
+        *(u32x2*)ep = packed;
+        if (inb) {
+          const float d0 = __uint_as_float(packed[0] << 16), d1 = __uint_as_float(packed[0] & 0xffff0000u);
+          const float d2 = __uint_as_float(packed[1] << 16), d3 = __uint_as_float(packed[1] & 0xffff0000u);
+          const float dd[4] = {d0, d1, d2, d3};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            l1[r] += dd[r];
+            l2[r] += dd[r] * (xv[r] - muv[r]) * rsv[r];
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+          l1[r] += __shfl_xor(l1[r], o, 64);
+          l2[r] += __shfl_xor(l2[r], o, 64);
+        }
+      }
+      if (j == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          atomicAdd(&gsm[(col + r) * 2], l1[r]);
+          atomicAdd(&gsm[(col + r) * 2 + 1], l2[r]);
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * CT) atomicAdd(&a.g_sums[((size_t)n * a.Cout + ct * CT) * 2 + tid], gsm[tid]);
+  } else {
+  // (B) registers -> (+bias, +residual) -> bf16 -> LDS tile; statistics accumulate in-lane over the 4 fragments
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int p = (8 * wm + 2 * i + (j >> 4)) * 16 + (j & 15);
@@ -592,6 +664,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma2_kernel(ConvArgs a) {
         }
       }
     }
+  }
   }
   __syncthreads();
   // (C) LDS tile -> global, 16 bytes per lane, consecutive lanes on consecutive addresses
@@ -815,9 +888,11 @@ extern "C" int pti_conv_pack_weights_batched(const void* table_dev, const int* b
   return PTI_OK;
 }
 
-extern "C" int pti_conv2d_mfma(const void* x, const void* w_packed, const float* bias, const float* in_stats,
-                               const float* gamma, const float* beta, const void* residual, void* y,
-                               float* out_stats, const pti_conv_desc* d, pti_stream_t s) {
+struct GnBwdFuse { int mode; const float* stats; const float* gamma; const float* beta; float* sums; };
+
+static int conv2d_mfma_impl(const void* x, const void* w_packed, const float* bias, const float* in_stats,
+                            const float* gamma, const float* beta, const void* residual, void* y,
+                            float* out_stats, const pti_conv_desc* d, const GnBwdFuse* gf, pti_stream_t s) {
   if (!x || !w_packed || !y || !d) PTI_FAIL(PTI_EINVAL, "conv2d_mfma: null pointer");
   if (d->cin % 32 || d->cout % 32 || d->cin <= 0 || d->cout <= 0)
     PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: cin=%d cout=%d must be positive multiples of 32", d->cin, d->cout);
@@ -851,8 +926,15 @@ extern "C" int pti_conv2d_mfma(const void* x, const void* w_packed, const float*
   a.out_stats = d->accum_stats ? out_stats : nullptr;
   a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Ho = d->ho; a.Wo = d->wo; a.Cout = d->cout;
   a.mode = d->mode; a.prologue = d->prologue; a.groups = d->groups; a.out_groups = d->out_groups;
+  a.gn_mode = 0; a.g_groups = 0; a.g_inv_cnt = 0.f; a.g_eps = 0.f;
+  a.g_stats = a.g_gamma = a.g_beta = nullptr; a.g_sums = nullptr;
   a.eps = d->eps;
   a.inv_cnt = d->prologue != PTI_PRO_NONE ? 1.0f / ((float)(d->cin / d->groups) * (float)d->h * (float)d->w) : 0.f;
+  if (gf) {
+    a.gn_mode = gf->mode; a.g_groups = d->groups; a.g_eps = d->eps;
+    a.g_inv_cnt = 1.0f / ((float)(d->cout / d->groups) * (float)d->ho * (float)d->wo);
+    a.g_stats = gf->stats; a.g_gamma = gf->gamma; a.g_beta = gf->beta; a.g_sums = gf->sums;
+  }
   a.tiles_x = cdiv(d->wo, TW); a.tiles_y = cdiv(d->ho, TH);
   const int cout_tile = pick_cout_tile(d->cout);
   int rc, ck;
@@ -866,4 +948,23 @@ extern "C" int pti_conv2d_mfma(const void* x, const void* w_packed, const float*
   if (rc != 0) PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: no kernel for ck=%d cout_tile=%d", ck, cout_tile);
   PTI_CHECK_LAUNCH("conv2d_mfma");
   return PTI_OK;
+}
+
+extern "C" int pti_conv2d_mfma(const void* x, const void* w_packed, const float* bias, const float* in_stats,
+                               const float* gamma, const float* beta, const void* residual, void* y,
+                               float* out_stats, const pti_conv_desc* d, pti_stream_t s) {
+  return conv2d_mfma_impl(x, w_packed, bias, in_stats, gamma, beta, residual, y, out_stats, d, nullptr, s);
+}
+
+extern "C" int pti_conv2d_mfma_gnbwd(const void* dy_in, const void* w_packed, const void* gx, const float* gstats,
+                                     const float* ggamma, const float* gbeta, void* dy_out, float* gsums,
+                                     const pti_conv_desc* d, int silu, pti_stream_t s) {
+  if (!gx || !gstats || !ggamma || !gbeta || !gsums || !d) PTI_FAIL(PTI_EINVAL, "conv2d_mfma_gnbwd: null pointer");
+  if (d->mode == PTI_CONV_S2PAD || d->prologue != PTI_PRO_NONE || d->add_residual || d->accum_stats)
+    PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma_gnbwd: plain stride-1 / zero-insert data-gradient launches only");
+  if (d->groups <= 0 || d->cout % d->groups) PTI_FAIL(PTI_EINVAL, "conv2d_mfma_gnbwd: groups must divide cout");
+  GnBwdFuse gf{silu ? 2 : 1, gstats, ggamma, gbeta, gsums};
+  pti_conv_desc dd = *d;
+  dd.add_residual = 1;   // the GN input rides the residual path into LDS
+  return conv2d_mfma_impl(dy_in, w_packed, nullptr, nullptr, nullptr, nullptr, gx, dy_out, nullptr, &dd, &gf, s);
 }

@@ -90,9 +90,11 @@ extern "C" int pti_gn_stats(const void* x, float* stats, int n, int hw, int c, i
   if (cpg < 8 && (8 % cpg)) PTI_FAIL(PTI_EUNSUPPORTED, "gn_stats: channels/group %d", cpg);
   if (cpg >= 8 && (cpg % 8)) PTI_FAIL(PTI_EUNSUPPORTED, "gn_stats: channels/group %d", cpg);
   const int ppi = 256 / (c / 8);
-  // aim for >= ~2048 blocks over the whole launch, each block a multiple of ppi pixels
+  // aim for ~2048 blocks over the whole launch, but never fewer than 16 iterations of ppi pixels per block
+  // (small tensors: the per-block prologue/epilogue would dominate)
   int bps = cdiv(2048, n);
   int ppb = cdiv(hw, bps);
+  if (ppb < 16 * ppi) ppb = 16 * ppi;
   ppb = cdiv(ppb, 4 * ppi) * 4 * ppi;
   bps = cdiv(hw, ppb);
   hipLaunchKernelGGL(gn_stats_kernel, dim3(bps, n), dim3(256), 2 * groups * sizeof(float), (hipStream_t)s,
@@ -293,11 +295,36 @@ extern "C" int pti_gn_bwd(const void* x, const void* da, const void* dres, void*
   const int ppi = 256 / (c / 8);
   int bps = cdiv(2048, n);
   int ppb = cdiv(hw, bps);
+  if (ppb < 16 * ppi) ppb = 16 * ppi;
   ppb = cdiv(ppb, ppi) * ppi;
   bps = cdiv(hw, ppb);
   a.ppb = ppb;
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(bps, n), dim3(256), 2 * c * sizeof(float), (hipStream_t)s, a);
   PTI_CHECK_LAUNCH("gn_bwd_reduce");
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(bps, n), dim3(256), 0, (hipStream_t)s, a);
+  PTI_CHECK_LAUNCH("gn_bwd_apply");
+  return PTI_OK;
+}
+
+// second half only: `dy` already is dA * act'(GN(x)) and `sums` already holds {sum dy, sum dy*xhat} per (n,c)
+// (both produced by pti_conv2d_mfma_gnbwd in the data-gradient conv's epilogue)
+extern "C" int pti_gn_bwd_apply(const void* x, const void* dy, const void* dres, void* dx, const float* stats,
+                                const float* gamma, const float* beta, const float* sums, float* dgamma, float* dbeta,
+                                int n, int hw, int c, int groups, float eps, pti_stream_t s) {
+  if (!x || !dy || !dx || !stats || !gamma || !beta || !sums) PTI_FAIL(PTI_EINVAL, "gn_bwd_apply: null pointer");
+  if (c < 8 || c > 2048 || (c & (c - 1)) || groups <= 0 || c % groups) PTI_FAIL(PTI_EUNSUPPORTED, "gn_bwd_apply: c=%d groups=%d", c, groups);
+  GnbArgs a;
+  a.x = (const bf16*)x; a.da = (const bf16*)dy; a.dres = (const bf16*)dres; a.dx = (bf16*)dx;
+  a.stats = stats; a.gamma = gamma; a.beta = beta; a.sums = const_cast<float*>(sums); a.dgamma = dgamma; a.dbeta = dbeta;
+  a.HW = hw; a.C = c; a.G = groups; a.silu = 0; a.eps = eps;
+  a.inv_cnt = 1.0f / ((float)(c / groups) * (float)hw);
+  const int ppi = 256 / (c / 8);
+  int bps = cdiv(2048, n);
+  int ppb = cdiv(hw, bps);
+  if (ppb < 16 * ppi) ppb = 16 * ppi;
+  ppb = cdiv(ppb, ppi) * ppi;
+  bps = cdiv(hw, ppb);
+  a.ppb = ppb;
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(bps, n), dim3(256), 0, (hipStream_t)s, a);
   PTI_CHECK_LAUNCH("gn_bwd_apply");
   return PTI_OK;

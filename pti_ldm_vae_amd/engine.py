@@ -105,6 +105,20 @@ class _MfmaConv:
             return pooled
         return out
 
+    def dgrad_gn(self, dy, x, norm, *, silu, dres, eng):
+        """Data gradient through  conv(act(GN(x)))  down to dx: the conv^T launch also does the GroupNorm
+        backward reduction (fused epilogue), pti_gn_bwd_apply finishes.  Stride-1 convs only."""
+        n, ho, wo, _ = dy.shape
+        dyt = _empty((n, ho, wo, self.cin), dy)
+        sums = eng.zeros(n * self.cin * 2)
+        ops.conv_mfma_gnbwd(dy, self.wpt, x.t, x.stats, norm.weight.data, norm.bias.data, dyt, sums, cout=self.cin,
+                            ksize=self.ksize, mode=PTI_CONV_S1, groups=eng.G, eps=eng.eps, silu=silu)
+        dx = _empty(x.t.shape, x.t)
+        ops.gn_bwd_apply(x.t, dyt, dx, x.stats, norm.weight.data, norm.bias.data, sums,
+                         norm.net.grad_view(norm.prefix + ".weight"), norm.net.grad_view(norm.prefix + ".bias"),
+                         groups=eng.G, eps=eng.eps, dres=dres)
+        return dx
+
     def wgrad(self, x, dy, *, pro=PTI_PRO_NONE, norm=None, eng=None):
         dw, db = self.grads()
         g, b = (norm.weight.data, norm.bias.data) if norm is not None else (None, None)
@@ -151,19 +165,15 @@ class _ResBlock:
 
     def bwd(self, dout, saved, eng):
         x, h1 = saved
-        da2 = self.conv2.dgrad(dout)
         self.conv2.wgrad(h1, dout, pro=PTI_PRO_GN_SILU, norm=self.norm2, eng=eng)
-        dh1 = self.norm2.bwd(h1, da2, silu=True, dres=None, eng=eng)
-        del da2
-        da1 = self.conv1.dgrad(dh1)
+        dh1 = self.conv2.dgrad_gn(dout, h1, self.norm2, silu=True, dres=None, eng=eng)
         self.conv1.wgrad(x, dh1, pro=PTI_PRO_GN_SILU, norm=self.norm1, eng=eng)
-        del dh1
         if self.nin is None:
             dres = dout
         else:
             dres = self.nin.dgrad(dout)
             self.nin.wgrad(x, dout, eng=eng)
-        return self.norm1.bwd(x, da1, silu=True, dres=dres, eng=eng)
+        return self.conv1.dgrad_gn(dh1, x, self.norm1, silu=True, dres=dres, eng=eng)
 
 
 class _Resample:
@@ -217,9 +227,8 @@ class _Attention:
         dqkv = _empty(qkv.shape, qkv)
         delta = _empty((n, h * w), qkv, F32)
         ops.attention_bwd(qkv.view(n, h * w, 3 * c), o, do.view(n, h * w, c), lse, delta, dqkv.view(n, h * w, 3 * c))
-        dxn = self.qkv.dgrad(dqkv)
         self.qkv.wgrad(x, dqkv, pro=PTI_PRO_GN, norm=self.norm, eng=eng)
-        return self.norm.bwd(x, dxn, silu=False, dres=dout, eng=eng)
+        return self.qkv.dgrad_gn(dqkv, x, self.norm, silu=False, dres=dout, eng=eng)
 
 
 class _DirectConv:

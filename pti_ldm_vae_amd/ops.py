@@ -120,17 +120,22 @@ def conv_mfma(x, w_packed, bias, y, *, cout, ksize=3, mode=PTI_CONV_S1, prologue
             "pti_conv2d_mfma")
     if prof is not None:
         e1.record()
-        s2 = mode == PTI_CONV_S2PAD
-        ck = 128 if cin % 128 == 0 else (64 if cin % 64 == 0 else 32)
-        ck = min(ck, 64) if s2 else ck
-        ct = 128 if cout % 128 == 0 else (64 if cout % 64 == 0 else 32)
-        name = f"conv_mfma_kernel<{ksize},{2 if s2 else 1},{ck},{ct}>"
+        name = _conv_kernel_name(ksize, mode, cin, cout)
         # algorithmic work; the zero-insert data gradient only has 1/4 useful taps per output pixel
         flops = 2.0 * n * ho * wo * cout * cin * ksize * ksize * (0.25 if mode == PTI_CONV_ZINS else 1.0)
         # algorithmic bytes: read the input once (bf16), write the output once (+ residual read)
         nbytes = 2.0 * (x.numel() + y.numel() * (2 if residual is not None else 1))
         prof.append((name, flops, nbytes, e0, e1))
     return y
+
+
+def _conv_kernel_name(ksize, mode, cin, cout):
+    """Template instantiation the C side picks (mirrors pick_cout_tile / pick_ck / pick_ck2), as rocprof names it."""
+    ct = 128 if cout % 128 == 0 else (64 if cout % 64 == 0 else 32)
+    ck = 128 if cin % 128 == 0 else (64 if cin % 64 == 0 else 32)
+    if mode == PTI_CONV_S2PAD:
+        return f"conv_mfma_kernel<3, 2, {min(ck, 64)}, {ct}>"
+    return f"conv_mfma2_kernel<{ksize}, {min(ck, ct)}, {ct}>"
 
 
 # Set to a list to make conv_mfma record (kernel name, algorithmic flops, bytes, start, end events) per
@@ -240,6 +245,48 @@ def gn_bwd(x, da, dx, stats, gamma, beta, sums, dgamma, dbeta, *, groups, eps=1e
     L.check(L.lib().pti_gn_bwd(_ptr(x), _ptr(da), _ptr(dres), _ptr(dx), _ptr(stats), _ptr(gamma), _ptr(beta),
                                _ptr(sums), _ptr(dgamma), _ptr(dbeta), n, h * w, c, groups, eps, int(silu), _stream()),
             "pti_gn_bwd")
+    return dx
+
+
+def conv_mfma_gnbwd(dy_in, w_packed_t, gx, gstats, ggamma, gbeta, dy_out, gsums, *, cout, ksize=3, mode=PTI_CONV_S1,
+                    groups=0, eps=1e-6, silu=True):
+    """Data-gradient conv with the GroupNorm(+SiLU) backward reduction fused into its epilogue:
+    dy_out = conv^T(dy_in) * act'(GN(gx)); gsums[n,c] += {sum dy_out, sum dy_out*xhat} (gsums zeroed by caller)."""
+    _chk(dy_in, BF16, "dy_in", 4)
+    _chk(gx, BF16, "gx", 4)
+    _chk(dy_out, BF16, "dy_out", 4)
+    n, h, w, cin = dy_in.shape
+    ho, wo = conv_out_hw(h, w, mode)
+    if tuple(dy_out.shape) != (n, ho, wo, cout) or gx.shape != dy_out.shape:
+        raise ValueError("conv_mfma_gnbwd: shapes")
+    if gsums.numel() != n * cout * 2 or gstats.numel() != n * groups * 2 or ggamma.numel() != cout:
+        raise ValueError("conv_mfma_gnbwd: GroupNorm buffers")
+    d = ConvDesc(n=n, h=h, w=w, cin=cin, ho=ho, wo=wo, cout=cout, ksize=ksize, mode=mode, groups=groups, eps=eps)
+    prof = KERNEL_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    L.check(L.lib().pti_conv2d_mfma_gnbwd(_ptr(dy_in), _ptr(w_packed_t), _ptr(gx), _ptr(gstats), _ptr(ggamma),
+                                          _ptr(gbeta), _ptr(dy_out), _ptr(gsums), C.byref(d), int(silu), _stream()),
+            "pti_conv2d_mfma_gnbwd")
+    if prof is not None:
+        e1.record()
+        prof.append((_conv_kernel_name(ksize, mode, cin, cout),
+                     2.0 * n * ho * wo * cout * cin * ksize * ksize * (0.25 if mode == PTI_CONV_ZINS else 1.0),
+                     2.0 * (dy_in.numel() + 2 * dy_out.numel()), e0, e1))
+    return dy_out
+
+
+def gn_bwd_apply(x, dy, dx, stats, gamma, beta, sums, dgamma, dbeta, *, groups, eps=1e-6, dres=None):
+    _chk(x, BF16, "x", 4)
+    _chk(dy, BF16, "dy", 4)
+    _chk(dx, BF16, "dx", 4)
+    n, h, w, c = x.shape
+    if dy.shape != x.shape or dx.shape != x.shape or (dres is not None and dres.shape != x.shape):
+        raise ValueError("gn_bwd_apply: shape mismatch")
+    L.check(L.lib().pti_gn_bwd_apply(_ptr(x), _ptr(dy), _ptr(dres), _ptr(dx), _ptr(stats), _ptr(gamma), _ptr(beta),
+                                     _ptr(sums), _ptr(dgamma), _ptr(dbeta), n, h * w, c, groups, eps, _stream()),
+            "pti_gn_bwd_apply")
     return dx
 
 
