@@ -98,8 +98,11 @@ def main():
     if world > 1:
         if int(os.environ.get("WORLD_SIZE", "1")) != world:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N (WORLD_SIZE must equal --gpus)")
+        # rehearsal knobs (single-GPU box): PTI_DIST_BACKEND=gloo PTI_SHARE_GPU=1 runs all ranks on cuda:0
+        if os.environ.get("PTI_SHARE_GPU") == "1":
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", init_method="env://")
+        dist.init_process_group(backend=os.environ.get("PTI_DIST_BACKEND", "nccl"), init_method="env://")
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
 
@@ -145,9 +148,10 @@ def main():
     roofline = None
     if rank == 0:
         ops.KERNEL_PROFILE = []
-        for _ in range(2):
-            trainer.step(images)
-        torch.cuda.synchronize()
+    for _ in range(2):          # EVERY rank steps (the step contains collectives); only rank 0 records
+        trainer.step(images)
+    torch.cuda.synchronize()
+    if rank == 0:
         rec, ops.KERNEL_PROFILE = ops.KERNEL_PROFILE, None
         agg = {}
         for name, flops, nbytes, e0, e1 in rec:
