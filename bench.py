@@ -163,8 +163,17 @@ def main():
         if agg:
             name, (tsec, flops, nbytes, cnt) = max(agg.items(), key=lambda kv: kv[1][0])
             ach = flops / tsec / 1e12
+            traffic = None   # HBM bytes per launch from the separate rocprofv3 --pmc passes committed under profiles/
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"].get(name)
+                if pmc:
+                    traffic = pmc["fetch_bytes"] + pmc["write_bytes"]
+            except (OSError, ValueError, KeyError):
+                pass
             roofline = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                        "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, avg per launch)",
+                        "algorithmic_bytes_per_launch": round(nbytes / cnt),
                         "launches_per_step": cnt // 2, "avg_launch_us": round(tsec / cnt * 1e6, 2),
                         "algorithmic_gflop_per_launch": round(flops / cnt / 1e9, 3),
                         "algorithmic_hbm_gbs": round(nbytes / tsec / 1e9, 1),
