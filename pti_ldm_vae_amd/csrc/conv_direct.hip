@@ -304,15 +304,20 @@ __global__ __launch_bounds__(256) void wgrad_direct_finalize_kernel(WGArgs a, in
   const int per = 80 * NC + 1;
   if (e >= per) return;
   const float* base = a.part + (size_t)k * nblocks * per + e;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
   int b = 0;
-  for (; b + 3 < nblocks; b += 4) {
+  for (; b + 7 < nblocks; b += 8) {
     s0 += base[(size_t)b * per];
     s1 += base[(size_t)(b + 1) * per];
     s2 += base[(size_t)(b + 2) * per];
     s3 += base[(size_t)(b + 3) * per];
+    s4 += base[(size_t)(b + 4) * per];
+    s5 += base[(size_t)(b + 5) * per];
+    s6 += base[(size_t)(b + 6) * per];
+    s7 += base[(size_t)(b + 7) * per];
   }
   for (; b < nblocks; ++b) s0 += base[(size_t)b * per];
+  s0 += s4; s1 += s5; s2 += s6; s3 += s7;
   const float v = (s0 + s1) + (s2 + s3);
   const int ntap = a.KS * a.KS;
   if (e == 80 * NC) {
@@ -399,7 +404,7 @@ extern "C" int pti_wgrad_direct(const void* wide, const void* narrow, float* dw,
   const long long npix = (long long)n * h * w;
   const int ppb = 256 / (cw / 8);
   long long blocks = (npix + ppb - 1) / ppb;
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > 1024) blocks = 1024;
   const long long per = 80 * (cw / 8) + 1;
   while (blocks > 1 && blocks * cn * per * 4 > workspace_bytes) blocks /= 2;
   if (blocks * cn * per * 4 > workspace_bytes) PTI_FAIL(PTI_EINVAL, "wgrad_direct: workspace too small");

@@ -208,14 +208,38 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnbArgs a) {
     mu[j] = mean; rs[j] = rstd; ga[j] = a.gamma[ch];
     sc[j] = rstd * ga[j];
     sh[j] = a.beta[ch] - mean * sc[j];
-    float t1 = 0.f, t2 = 0.f;
-    for (int cc = g * cpg; cc < (g + 1) * cpg; ++cc) {
-      const float gm = a.gamma[cc];
-      t1 += gm * a.sums[((size_t)n * a.C + cc) * 2];
-      t2 += gm * a.sums[((size_t)n * a.C + cc) * 2 + 1];
+    c1[j] = c2[j] = 0.f;
+    if (cpg > 8) {   // group spans several 8-channel pieces: walk it (rare: >8 channels per group)
+      float t1 = 0.f, t2 = 0.f;
+      for (int cc = g * cpg; cc < (g + 1) * cpg; ++cc) {
+        const float gm = a.gamma[cc];
+        t1 += gm * a.sums[((size_t)n * a.C + cc) * 2];
+        t2 += gm * a.sums[((size_t)n * a.C + cc) * 2 + 1];
+      }
+      c1[j] = t1 * a.inv_cnt;
+      c2[j] = t2 * a.inv_cnt;
     }
-    c1[j] = t1 * a.inv_cnt;
-    c2[j] = t2 * a.inv_cnt;
+  }
+  if (cpg <= 8) {    // whole groups live inside this thread's 8 channels: 16 loads, no dependent walk
+    float w1[8], w2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const f32x2 sv = *(const f32x2*)(a.sums + ((size_t)n * a.C + lc * 8 + j) * 2);
+      w1[j] = ga[j] * sv[0];
+      w2[j] = ga[j] * sv[1];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const bool same = (jj / cpg) == (j / cpg);
+        t1 += same ? w1[jj] : 0.f;
+        t2 += same ? w2[jj] : 0.f;
+      }
+      c1[j] = t1 * a.inv_cnt;
+      c2[j] = t2 * a.inv_cnt;
+    }
   }
   if (blockIdx.x == 0) {  // per-sample contribution to the affine gradients: N adds per address in total
     for (int i = tid; i < a.C; i += 256) {

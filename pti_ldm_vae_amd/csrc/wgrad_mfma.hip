@@ -256,6 +256,183 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgArgs a) {
   }
 }
 
+// =============================================================================================
+// v3 (3x3, stride-1 gathers): 32co x 32ci block per workgroup, THREE waves, wave = kernel row kh.
+// Measured on v1 (144 accumulator VGPRs per wave => 2 waves/SIMD, one 20 KB tile in flight per workgroup):
+// the loop is bound by HBM latency x bytes in flight (Little's law), ~2-3 TB/s.  Splitting the 9 taps over
+// three waves leaves 48 accumulator VGPRs per wave => ~5 workgroups per CU, i.e. ~100 KB of loads in flight
+// per CU, and removes the cross-wave accumulator reduction of the pixel-split form.
+// =============================================================================================
+struct W3Cfg {
+  static constexpr int TH = 8, HH = TH + 2, HW = TW + 2, NP = HH * HW;
+  static constexpr int PP = 64;                                  // bytes per pixel (32 channels bf16)
+  static constexpr int A_BYTES = NP * PP, D_BYTES = TH * TW * PP;
+  static constexpr int NT = 192;
+  static constexpr int HIT = (NP * 4 + NT - 1) / NT, DIT = (TH * TW * 4 + NT - 1) / NT;
+  static constexpr int LDS_BYTES = A_BYTES + D_BYTES;
+};
+
+__global__ __launch_bounds__(192) void wgrad_mfma3_kernel(WgArgs a) {
+  using C = W3Cfg;
+  typedef short v4s __attribute__((ext_vector_type(4)));
+  typedef short v8s __attribute__((ext_vector_type(8)));
+  __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS_BYTES];
+  unsigned char* lA = smem;
+  unsigned char* lD = smem + C::A_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, kh = tid >> 6;
+  const int split = blockIdx.y;
+  const int cot = blockIdx.x / a.ci_tiles, cit = blockIdx.x % a.ci_tiles;
+  const bool twox = (a.mode == PTI_CONV_UP2);
+  const int VH = twox ? 2 * a.H : a.H, VW = twox ? 2 * a.W : a.W;
+
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const int pk = 8 * (g >> 1) + q, chl = 16 * (g & 1) + 4 * pp;
+  const int fbase = pk * C::PP + chl * 2;
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bsum[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
+
+  const int lc = tid & 3, lp = tid >> 2;            // piece within a pixel / pixel index step 48
+  constexpr int PSTEP = C::NT / 4;
+  const int cpg = a.Cin / (a.groups > 0 ? a.groups : 1);
+  int cur_n = -1;
+  float sc[8], sh[8];
+  u32x4 araw[C::HIT], draw[C::DIT];
+  unsigned aokm = 0;
+
+  auto issue = [&](int tile) -> int {
+    int t = tile;
+    const int tx_ = t % a.tiles_x; t /= a.tiles_x;
+    const int ty_ = t % a.tiles_y;
+    const int n = t / a.tiles_y;
+    const int oy0 = ty_ * C::TH, ox0 = tx_ * TW;
+#pragma unroll
+    for (int it = 0; it < C::HIT; ++it) {
+      const int p = lp + it * PSTEP;
+      const int hy = p / C::HW, hx = p - hy * C::HW;
+      const int vy = oy0 - 1 + hy, vx = ox0 - 1 + hx;
+      const bool v = (p < C::NP) && vy >= 0 && vy < VH && vx >= 0 && vx < VW;
+      const int iy = twox ? (vy >> 1) : vy, ix = twox ? (vx >> 1) : vx;
+      aokm = (aokm & ~(1u << it)) | ((unsigned)v << it);
+      araw[it] = u32x4{0u, 0u, 0u, 0u};
+      if (v) araw[it] = *(const u32x4*)(a.x + ((size_t)(n * a.H + iy) * a.W + ix) * a.Cin + cit * 32 + lc * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < C::DIT; ++it) {
+      const int p = lp + it * PSTEP;
+      const int oy = oy0 + p / TW, ox = ox0 + p % TW;
+      draw[it] = u32x4{0u, 0u, 0u, 0u};
+      if (p < C::TH * TW && oy < a.Ho && ox < a.Wo)
+        draw[it] = *(const u32x4*)(a.dy + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.Cout + cot * 32 + lc * 8);
+    }
+    return n;
+  };
+  auto commit = [&](int n) {
+    if (a.prologue != PTI_PRO_NONE && n != cur_n) {
+      cur_n = n;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int ch = cit * 32 + lc * 8 + j;
+        const int gg = ch / cpg;
+        const float sum = a.in_stats[(n * a.groups + gg) * 2], sq = a.in_stats[(n * a.groups + gg) * 2 + 1];
+        const float mean = sum * a.inv_cnt;
+        const float rstd = rsqrtf(fmaxf(sq * a.inv_cnt - mean * mean, 0.f) + a.eps);
+        sc[j] = rstd * a.gamma[ch];
+        sh[j] = a.beta[ch] - mean * sc[j];
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < C::HIT; ++it) {
+      const int p = lp + it * PSTEP;
+      if (p < C::NP) {
+        u32x4 r = araw[it];
+        if (a.prologue != PTI_PRO_NONE && ((aokm >> it) & 1u)) {
+          float f[8];
+          unpack8(r, f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float v = f[j] * sc[j] + sh[j];
+            if (a.prologue == PTI_PRO_GN_SILU) v = silu_f(v);
+            f[j] = v;
+          }
+          r = pack8(f);
+        }
+        *(u32x4*)(lA + p * C::PP + lc * 16) = r;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < C::DIT; ++it) {
+      const int p = lp + it * PSTEP;
+      if (p < C::TH * TW) {
+        *(u32x4*)(lD + p * C::PP + lc * 16) = draw[it];
+        if (cit == 0) {
+          float f[8];
+          unpack8(draw[it], f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bsum[j] += f[j];
+        }
+      }
+    }
+  };
+
+  int tile = split, n_next = -1;
+  if (tile < a.ntiles) n_next = issue(tile);
+  for (; tile < a.ntiles; tile += a.S) {
+    commit(n_next);
+    __syncthreads();
+    const int nxt = tile + a.S;
+    if (nxt < a.ntiles) n_next = issue(nxt);
+#pragma unroll
+    for (int row = 0; row < C::TH; ++row) {
+      const unsigned char* dptr = lD + fbase + row * TW * C::PP;
+      const v4s d0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(dptr));
+      const v4s d1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(dptr + 4 * C::PP));
+      v8s td = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+      const bf16x8 dfrag = __builtin_bit_cast(bf16x8, td);
+      const unsigned char* arow = lA + fbase + (row + kh) * C::HW * C::PP;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const unsigned char* aptr = arow + kw * C::PP;
+        const v4s a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(aptr));
+        const v4s a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(aptr + 4 * C::PP));
+        v8s ta = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfrag, __builtin_bit_cast(bf16x8, ta), acc[kw], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: wave kh owns taps kh*3 .. kh*3+2 of the slab [tap][co][ci] ----
+  float* slab = a.slab + (size_t)split * a.slab_stride;
+  const int ci = cit * 32 + (lane & 31);
+  const int hsel = lane >> 5;
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = cot * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
+      slab[((size_t)(kh * 3 + kw) * a.Cout + co) * a.Cin + ci] = acc[kw][r];
+    }
+  if (cit == 0) {   // bias partials: threads with equal lc hold the same 8 channels
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[j * C::NT + tid] = bsum[j];
+    __syncthreads();
+    if (tid < 32) {
+      const int c4 = tid / 8, j = tid % 8;
+      float sm = 0.f;
+      for (int k = c4; k < C::NT; k += 4) sm += red[j * C::NT + k];
+      slab[(size_t)9 * a.Cout * a.Cin + cot * 32 + tid] = sm;
+    }
+  }
+}
+
 // dW[co][ci][tap] (=|+=) sum_s slab[s][tap][co][ci];  dbias[co] (=|+=) sum_s slab[s][KK*Cout*Cin + co]
 // block = 16 float4 columns (64 consecutive slab elements) x 16 slab groups: slabs are summed by 16 threads in
 // parallel (fixed order => deterministic), folded through LDS, and written by the first group.
@@ -350,7 +527,16 @@ extern "C" int pti_conv_wgrad_mfma(const void* x, const void* dy, const float* i
   if (S < 1) PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma: workspace too small (%lld bytes per split needed)", a.slab_stride * 4);
   a.S = S;
   hipStream_t st = (hipStream_t)s;
-  if (d->ksize == 1) launch_wt<1, 1>(a, co_t, ci_t, tiles_cc, st);
+  if (d->ksize == 3 && d->mode != PTI_CONV_S2PAD && co_t == 32 && ci_t == 32) {
+    // v3: three waves per workgroup (one per kernel row), ~5 workgroups per CU
+    int S3 = 1280 / tiles_cc;
+    if (S3 > a.ntiles / 4) S3 = a.ntiles / 4;
+    if (S3 > 512) S3 = 512;
+    if (S3 < 1) S3 = 1;
+    if (S3 > smax) S3 = (int)smax;
+    a.S = S = S3;
+    hipLaunchKernelGGL(wgrad_mfma3_kernel, dim3(tiles_cc, S3), dim3(192), 0, st, a);
+  } else if (d->ksize == 1) launch_wt<1, 1>(a, co_t, ci_t, tiles_cc, st);
   else if (d->mode == PTI_CONV_S2PAD) launch_wt<3, 2>(a, co_t, ci_t, tiles_cc, st);
   else launch_wt<3, 1>(a, co_t, ci_t, tiles_cc, st);
   PTI_CHECK_LAUNCH("conv_wgrad_mfma");
