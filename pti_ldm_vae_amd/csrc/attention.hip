@@ -185,18 +185,28 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const bf16* __rest
                                                               const float* __restrict__ delta, bf16* __restrict__ dqkv,
                                                               int L, float c_log2, float scale) {
   using C = ACfg<D>;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[(2 * TB + 2 * C::KT) * C::P];
+  constexpr bool REGQ = (D <= 128);   // Q / dO fragments live in registers: LDS only holds the streamed K/V tile
+  __shared__ __attribute__((aligned(16))) unsigned char smem[((REGQ ? 0 : 2 * TB) + 2 * C::KT) * C::P];
   unsigned char* sQ = smem;
-  unsigned char* sDO = sQ + TB * C::P;
-  unsigned char* sK = sDO + TB * C::P;
+  unsigned char* sDO = sQ + (REGQ ? 0 : TB) * C::P;
+  unsigned char* sK = sDO + (REGQ ? 0 : TB) * C::P;
   unsigned char* sV = sK + C::KT * C::P;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y, qb0 = blockIdx.x * TB;
   const size_t rs = 3 * D;
   const bf16* base = qkv + (size_t)b * L * rs;
-  load_rows<D, 64 * NW>(sQ, base + (size_t)qb0 * rs, rs, TB, tid);
-  load_rows<D, 64 * NW>(sDO, dout + ((size_t)b * L + qb0) * D, D, TB, tid);
   const int qi = qb0 + wave * 32 + (lane & 31);
+  bf16x8 bq[REGQ ? C::KS : 1], bdo[REGQ ? C::KS : 1];
+  if constexpr (REGQ) {
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      bq[ks] = *(const bf16x8*)(base + (size_t)qi * rs + 16 * ks + 8 * (lane >> 5));
+      bdo[ks] = *(const bf16x8*)(dout + ((size_t)b * L + qi) * D + 16 * ks + 8 * (lane >> 5));
+    }
+  } else {
+    load_rows<D, 64 * NW>(sQ, base + (size_t)qb0 * rs, rs, TB, tid);
+    load_rows<D, 64 * NW>(sDO, dout + ((size_t)b * L + qb0) * D, D, TB, tid);
+  }
   const float my_lse = lse2[(size_t)b * L + qi], my_delta = delta[(size_t)b * L + qi];
   f32x16 dq[C::DB];
 #pragma unroll
@@ -216,8 +226,11 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const bf16* __rest
       for (int r = 0; r < 16; ++r) sa[r] = dp[r] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < C::KS; ++ks) {
-        sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sK, kb * 32, ks, lane), frag_row<D>(sQ, wave * 32, ks, lane), sa, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sV, kb * 32, ks, lane), frag_row<D>(sDO, wave * 32, ks, lane), dp, 0, 0, 0);
+        bf16x8 fq, fdo;
+        if constexpr (REGQ) { fq = bq[ks]; fdo = bdo[ks]; }
+        else { fq = frag_row<D>(sQ, wave * 32, ks, lane); fdo = frag_row<D>(sDO, wave * 32, ks, lane); }
+        sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sK, kb * 32, ks, lane), fq, sa, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sV, kb * 32, ks, lane), fdo, dp, 0, 0, 0);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -252,10 +265,11 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkdv_kernel(const bf16* __re
                                                                 int L, float c_log2, float scale) {
   using C = ACfg<D>;
   constexpr int DBL = C::DB / DSPLIT;  // d blocks accumulated by this workgroup
-  __shared__ __attribute__((aligned(16))) unsigned char smem[(2 * TB + 2 * C::KT) * C::P + 2 * C::KT * 4];
+  constexpr bool REGK = (D <= 128);    // K / V fragments of the owned keys live in registers
+  __shared__ __attribute__((aligned(16))) unsigned char smem[((REGK ? 0 : 2 * TB) + 2 * C::KT) * C::P + 2 * C::KT * 4];
   unsigned char* sK = smem;
-  unsigned char* sV = sK + TB * C::P;
-  unsigned char* sQ = sV + TB * C::P;
+  unsigned char* sV = sK + (REGK ? 0 : TB) * C::P;
+  unsigned char* sQ = sV + (REGK ? 0 : TB) * C::P;
   unsigned char* sDO = sQ + C::KT * C::P;
   float* sL = reinterpret_cast<float*>(sDO + C::KT * C::P);
   float* sDl = sL + C::KT;
@@ -263,8 +277,18 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkdv_kernel(const bf16* __re
   const int b = blockIdx.y, kb0 = blockIdx.x * TB, dz = blockIdx.z * DBL;
   const size_t rs = 3 * D;
   const bf16* base = qkv + (size_t)b * L * rs;
-  load_rows<D, 64 * NW>(sK, base + (size_t)kb0 * rs + D, rs, TB, tid);
-  load_rows<D, 64 * NW>(sV, base + (size_t)kb0 * rs + 2 * D, rs, TB, tid);
+  bf16x8 bk[REGK ? C::KS : 1], bv[REGK ? C::KS : 1];
+  if constexpr (REGK) {
+    const bf16* krow = base + (size_t)(kb0 + wave * 32 + (lane & 31)) * rs + 8 * (lane >> 5);
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      bk[ks] = *(const bf16x8*)(krow + D + 16 * ks);
+      bv[ks] = *(const bf16x8*)(krow + 2 * D + 16 * ks);
+    }
+  } else {
+    load_rows<D, 64 * NW>(sK, base + (size_t)kb0 * rs + D, rs, TB, tid);
+    load_rows<D, 64 * NW>(sV, base + (size_t)kb0 * rs + 2 * D, rs, TB, tid);
+  }
   f32x16 dk[DBL], dv[DBL];
 #pragma unroll
   for (int d = 0; d < DBL; ++d)
@@ -288,8 +312,11 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkdv_kernel(const bf16* __re
       for (int r = 0; r < 16; ++r) sa[r] = dp[r] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < C::KS; ++ks) {
-        sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sQ, qb * 32, ks, lane), frag_row<D>(sK, wave * 32, ks, lane), sa, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sDO, qb * 32, ks, lane), frag_row<D>(sV, wave * 32, ks, lane), dp, 0, 0, 0);
+        bf16x8 fk, fv;
+        if constexpr (REGK) { fk = bk[ks]; fv = bv[ks]; }
+        else { fk = frag_row<D>(sK, wave * 32, ks, lane); fv = frag_row<D>(sV, wave * 32, ks, lane); }
+        sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sQ, qb * 32, ks, lane), fk, sa, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sDO, qb * 32, ks, lane), fv, dp, 0, 0, 0);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {

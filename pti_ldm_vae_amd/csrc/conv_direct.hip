@@ -211,14 +211,14 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(WGArgs a) {
     for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
 #pragma unroll
   for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
+  // "wide" is the centre of the stencil: one 16-byte load (+ prologue, applied ONCE) per pixel piece, multiplied with
+  // the K*K neighbouring narrow scalars (4-byte, cache resident):  dW[tap][cw] = sum_p' wide[p'] * narrow[p' - sgn*off]
   for (long long pix0 = (long long)blockIdx.x * ppb; pix0 < npix; pix0 += (long long)gridDim.x * ppb) {
     const long long pix = pix0 + lp;
     if (pix >= npix) continue;
     const int ox = pix % a.W;
     const int oy = (pix / a.W) % a.H;
     const int n = pix / ((long long)a.W * a.H);
-    const float nv = ld_narrow(a.narrow, n * a.ns[0] + oy * a.ns[1] + ox * a.ns[2] + k * a.ns[3], a.narrow_f32);
-    nsum += nv;
     if (a.prologue && n != cur_n) {
       cur_n = n;
 #pragma unroll
@@ -231,30 +231,31 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(WGArgs a) {
         sh[j] = a.beta[ch] - mean * sc[j];
       }
     }
+    float f[8];
+    unpack8(*(const u32x4*)(a.wide + (size_t)pix * a.CW + lc * 8), f);
     if (a.dbias_wide && k == 0) {
-      float f[8];
-      unpack8(*(const u32x4*)(a.wide + (size_t)pix * a.CW + lc * 8), f);
 #pragma unroll
       for (int j = 0; j < 8; ++j) bsum[j] += f[j];
     }
+    if (a.prologue) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float v = f[j] * sc[j] + sh[j];
+        if (a.prologue == PTI_PRO_GN_SILU) v = silu_f(v);
+        f[j] = v;
+      }
+    }
+    nsum += ld_narrow(a.narrow, n * a.ns[0] + oy * a.ns[1] + ox * a.ns[2] + k * a.ns[3], a.narrow_f32);
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
         if (kh < a.KS && kw < a.KS) {
-          const int iy = oy + a.sgn * (kh - pad), ix = ox + a.sgn * (kw - pad);
+          const int iy = oy - a.sgn * (kh - pad), ix = ox - a.sgn * (kw - pad);
           if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
-            float f[8];
-            unpack8(*(const u32x4*)(a.wide + ((size_t)(n * a.H + iy) * a.W + ix) * a.CW + lc * 8), f);
+            const float nv = ld_narrow(a.narrow, n * a.ns[0] + iy * a.ns[1] + ix * a.ns[2] + k * a.ns[3], a.narrow_f32);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              float v = f[j];
-              if (a.prologue) {
-                v = v * sc[j] + sh[j];
-                if (a.prologue == PTI_PRO_GN_SILU) v = silu_f(v);
-              }
-              acc[kh * 3 + kw][j] += nv * v;
-            }
+            for (int j = 0; j < 8; ++j) acc[kh * 3 + kw][j] += nv * f[j];
           }
         }
       }

@@ -357,7 +357,9 @@ struct Cfg2 {
   static constexpr int NT = CT / 32;
   static constexpr int KPC = CK / 16;
   static constexpr int KBC = KS * KS * KPC;
-  static constexpr int R = (KS == 3) ? 9 : KBC;   // register ring depth; always divides KBC
+  // weight fragments per register set (two sets alternate); divides KBC with an even quotient for 3x3.
+  // (tried: R = 3 + 3 workgroups/CU for CK = 32 -> spills, 30 % slower)
+  static constexpr int R = (KS == 3) ? 9 : KBC;
   static constexpr int HALO_BYTES = NP * PIXB;
   static constexpr int KEY_SHIFT = (NC == 16) ? 0 : (NC == 8 ? 1 : 2);
   static constexpr int HITERS = (NP * NC + 255) / 256;
