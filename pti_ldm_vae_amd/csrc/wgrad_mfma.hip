@@ -514,6 +514,7 @@ extern "C" int pti_conv_wgrad_mfma(const void* x, const void* dy, const float* i
   // the partial-slab traffic (S x full dW) stays small.
   int co_t = d->cout % 64 == 0 ? 64 : 32, ci_t = d->cin % 64 == 0 ? 64 : 32;
   if ((long long)a.ntiles * (d->cout / co_t) * (d->cin / ci_t) < 16 * 512) co_t = ci_t = 32;
+  if (d->ksize == 3 && d->mode != PTI_CONV_S2PAD) co_t = ci_t = 32;   // v3 (tap-split, 32x32) measured faster on every 3x3 shape
   a.ci_tiles = d->cin / ci_t;
   const int tiles_cc = (d->cout / co_t) * a.ci_tiles;
   const int kk = d->ksize * d->ksize;
