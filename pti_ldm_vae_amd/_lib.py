@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpti_vae_hip.so")
+LIB_PATH = os.environ.get("PTI_VAE_LIB") or os.path.join(_HERE, "libpti_vae_hip.so")   # env: kernel-variant A/B runs
 
 PTI_CONV_S1, PTI_CONV_S2PAD, PTI_CONV_UP2, PTI_CONV_ZINS = 0, 1, 2, 3
 PTI_PRO_NONE, PTI_PRO_GN, PTI_PRO_GN_SILU = 0, 1, 2

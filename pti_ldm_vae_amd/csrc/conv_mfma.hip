@@ -338,7 +338,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
 // x 32 output channels, and streams its weight fragments straight from global/L2 into an 8-deep
 // register ring (the packed layout makes every fragment one coalesced 1-KiB wave load), so the main
 // loop has no LDS writes and no barriers; 4 MFMAs are issued per 4 ds_read_b128 + 1 global load.
-// Workgroup = 4 waves = (4/WN) pixel groups x WN cout fragments, i.e. 128*WM pixels x CT channels.
+// Workgroup = 4 waves = (4/WN) pixel groups x WN cout fragments, i.e. 32*PXF*WM pixels x CT channels.
+// PXF (MFMA pixel fragments per wave) is 4 for the 128-channel tiles (MFMA-bound, 2 workgroups/CU) and 2 for
+// the 32/64-channel tiles: those layers are HBM-latency-bound, and halving the accumulators + a 3-deep weight
+// ring fits 4 workgroups/CU (128 VGPRs) -- measured 32->32@256^2 100.6 -> 81.4 us, 64->32 159 -> 133 us.
+// (tried: PXF = 1 -> more weight traffic per MFMA and 1.4-1.7x halo amplification, 1.5x slower.)
 // =============================================================================================
 __host__ __device__ constexpr int pick_ck2(int cin, int ct) {
   const int ck = cin % 128 == 0 ? 128 : (cin % 64 == 0 ? 64 : 32);
@@ -346,10 +350,34 @@ __host__ __device__ constexpr int pick_ck2(int cin, int ct) {
   return ck < cap ? ck : cap;
 }
 
-template <int KS, int CK, int CT>
+// Sum NV per-lane values over the 32 lanes of each wave half with NV-1 (+ log2(32/NV)) shuffles instead of
+// 5*NV: at every level a lane keeps one half of its values and trades the other half with its partner.
+// Afterwards v[0] of lane j holds the total of value index  (j & 31) >> (5 - log2 NV)  (all lanes of that
+// index hold the same total).
+template <int NV, int N, int O>
+__device__ __forceinline__ void fold32_level(float (&v)[NV], int j) {
+  if constexpr (O >= 1) {
+    if constexpr (N > 1) {
+      const bool hi = (j & O) != 0;
+#pragma unroll
+      for (int i = 0; i < N / 2; ++i) {
+        const float send = hi ? v[i] : v[i + N / 2];
+        const float keep = hi ? v[i + N / 2] : v[i];
+        v[i] = keep + __shfl_xor(send, O, 64);
+      }
+    } else {
+      v[0] += __shfl_xor(v[0], O, 64);
+    }
+    fold32_level<NV, (N > 1 ? N / 2 : 1), O / 2>(v, j);
+  }
+}
+template <int NV>
+__device__ __forceinline__ void fold32(float (&v)[NV], int j) { fold32_level<NV, NV, 16>(v, j); }
+
+template <int KS, int CK, int CT, int PXF>
 struct Cfg2 {
   static constexpr int WN = CT / 32, WM = 4 / WN;
-  static constexpr int TH2 = 8 * WM, TW2 = 16;
+  static constexpr int TH2 = 2 * PXF * WM, TW2 = 16;   // PXF = MFMA pixel fragments (2 rows x 16) per wave
   static constexpr int HH = TH2 + KS - 1, HW = TW2 + KS - 1;
   static constexpr int NP = HH * HW;
   static constexpr int NC = CK / 8;
@@ -359,13 +387,14 @@ struct Cfg2 {
   static constexpr int KBC = KS * KS * KPC;
   // weight fragments per register set (two sets alternate); divides KBC with an even quotient for 3x3.
   // (tried: R = 3 + 3 workgroups/CU for CK = 32 -> spills, 30 % slower)
-  static constexpr int R = (KS == 3) ? 9 : KBC;
+  static constexpr int R = (KS == 3) ? (PXF == 2 ? 3 : 9) : KBC;
+  static constexpr int WGS_PER_CU = PXF == 2 ? 4 : 2;
   static constexpr int HALO_BYTES = NP * PIXB;
   static constexpr int KEY_SHIFT = (NC == 16) ? 0 : (NC == 8 ? 1 : 2);
   static constexpr int HITERS = (NP * NC + 255) / 256;
   // epilogue: the 128*WM x CT output tile is transposed through LDS ([pixel][CT] bf16, padded pitch) so that
   // global stores / residual loads are 16-byte pieces with consecutive lanes on consecutive addresses
-  static constexpr int MPX = 128 * WM;
+  static constexpr int MPX = 32 * PXF * WM;
   static constexpr int EPITCH = CT * 2 + 16;
   static constexpr int EPI_BYTES = MPX * EPITCH;
   static constexpr int ENC = CT / 8;                      // 16-byte pieces per pixel of the tile
@@ -374,9 +403,9 @@ struct Cfg2 {
   static constexpr int LDS_BYTES = STAT_OFF + 1024;
 };
 
-template <int KS, int CK, int CT>
-__global__ __launch_bounds__(256, 2) void conv_mfma2_kernel(ConvArgs a) {
-  using C = Cfg2<KS, CK, CT>;
+template <int KS, int CK, int CT, int PXF>
+__global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(ConvArgs a) {
+  using C = Cfg2<KS, CK, CT, PXF>;
   __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS_BYTES];
   unsigned char* halo = smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -399,7 +428,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma2_kernel(ConvArgs a) {
   // per-lane LDS addresses of the pixel (B) fragments: fragment i = tile rows 8*wm + 2i, +1
   int pbase[KS], tkey[KS];
   {
-    const int j = lane & 31, tx = j & 15, row0 = 8 * wm + (j >> 4);
+    const int j = lane & 31, tx = j & 15, row0 = 2 * PXF * wm + (j >> 4);
 #pragma unroll
     for (int kw = 0; kw < KS; ++kw) {
       const int hx = tx + kw;
@@ -407,9 +436,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma2_kernel(ConvArgs a) {
       pbase[kw] = (row0 * C::HW + hx) * C::PIXB;
     }
   }
-  f32x16 acc[4];
+  f32x16 acc[PXF];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < PXF; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
@@ -417,6 +446,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma2_kernel(ConvArgs a) {
   constexpr int PSTEP = 256 / C::NC;
   const int cpg = a.Cin / (a.groups > 0 ? a.groups : 1);
   reinterpret_cast<float*>(smem + C::STAT_OFF)[tid] = 0.f;   // visible after the first barrier below
+
+  // (tried: fetching the residual tile to registers under the last chunk's MFMA loop -> spills at the
+  //  128-VGPR cap of the 4-workgroup/CU shapes, 1.9x slower)
+  const int epc = tid % C::ENC, epp0 = tid / C::ENC;
+  constexpr int EPSTEP = 256 / C::ENC;
 
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     // weight fragments of this (cout tile, cin chunk): [kb][nt][lane][8]; start the ring first so the
@@ -502,11 +536,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma2_kernel(ConvArgs a) {
       const int tk = (hsel ^ ((hx >> C::KEY_SHIFT) & (C::NC - 1))) << 4;
       return halo + pbase[0] + (kh * C::HW + kw) * C::PIXB + ((kc * 32) ^ tk);
     };
-    bf16x8 b0[4], b1[4];
-    auto bread = [&](bf16x8 (&dst)[4], int kb) {
+    bf16x8 b0[PXF], b1[PXF];
+    auto bread = [&](bf16x8 (&dst)[PXF], int kb) {
       const unsigned char* bp = baddr(kb);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) dst[i] = *(const bf16x8*)(bp + 2 * i * C::HW * C::PIXB);
+      for (int i = 0; i < PXF; ++i) dst[i] = *(const bf16x8*)(bp + 2 * i * C::HW * C::PIXB);
     };
     auto group = [&](const bf16x8 (&w)[C::R], int g) {
       const int kb0 = g * C::R;
@@ -515,16 +549,16 @@ __global__ __launch_bounds__(256, 2) void conv_mfma2_kernel(ConvArgs a) {
         if ((u & 1) == 0) {
           bread(b1, kb0 + u + 1);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[u], b0[i], acc[i], 0, 0, 0);
+          for (int i = 0; i < PXF; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[u], b0[i], acc[i], 0, 0, 0);
         } else {
           bread(b0, kb0 + u + 1);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[u], b1[i], acc[i], 0, 0, 0);
+          for (int i = 0; i < PXF; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[u], b1[i], acc[i], 0, 0, 0);
         }
       }
       if (C::R & 1) {  // odd group length: the last read went to b1/b0 alternately; realign so b0 is current
 #pragma unroll
-        for (int i = 0; i < 4; ++i) b0[i] = b1[i];
+        for (int i = 0; i < PXF; ++i) b0[i] = b1[i];
       }
     };
     constexpr int NG = C::KBC / C::R;
@@ -549,8 +583,6 @@ __global__ __launch_bounds__(256, 2) void conv_mfma2_kernel(ConvArgs a) {
   const int ocpg = do_stats ? a.Cout / a.out_groups : 1;
   __syncthreads();  // every wave is done with the halo tile
   // (A) residual tile -> LDS with coalesced 16-byte loads
-  const int epc = tid % C::ENC, epp0 = tid / C::ENC;
-  constexpr int EPSTEP = 256 / C::ENC;
   if (a.res) {
 #pragma unroll
     for (int it = 0; it < C::EITERS; ++it) {
@@ -570,6 +602,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma2_kernel(ConvArgs a) {
     // (B') data gradient + GroupNorm backward reduction: etile holds the GN input gx
     const int gcpg = a.Cout / a.g_groups;
     float* gsm = reinterpret_cast<float*>(smem + C::STAT_OFF);   // [CT][2], zeroed before the main loop
+    float L[32];   // [q][r][{sum dy, sum dy*xhat}] of this lane
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int col = col0 + 8 * q, ch0 = ct * CT + col;
@@ -585,8 +618,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma2_kernel(ConvArgs a) {
         shv[r] = a.g_beta[ch0 + r] - mean * scv[r];
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int p = (8 * wm + 2 * i + (j >> 4)) * 16 + (j & 15);
+      for (int i = 0; i < PXF; ++i) {
+        const int p = (2 * PXF * wm + 2 * i + (j >> 4)) * 16 + (j & 15);
         const bool inb = (oy0 + (p >> 4) < a.Ho) && (ox0 + (p & 15) < a.Wo);
         unsigned char* ep = etile + p * C::EPITCH + col * 2;
         const u32x2 rr = *(const u32x2*)ep;
@@ -614,27 +647,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma2_kernel(ConvArgs a) {
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) {
-          l1[r] += __shfl_xor(l1[r], o, 64);
-          l2[r] += __shfl_xor(l2[r], o, 64);
-        }
-      }
-      if (j == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          atomicAdd(&gsm[(col + r) * 2], l1[r]);
-          atomicAdd(&gsm[(col + r) * 2 + 1], l2[r]);
-        }
+        L[8 * q + 2 * r] = l1[r];
+        L[8 * q + 2 * r + 1] = l2[r];
       }
     }
-    __syncthreads();
-    if (tid < 2 * CT) atomicAdd(&a.g_sums[((size_t)n * a.Cout + ct * CT) * 2 + tid], gsm[tid]);
+    fold32<32>(L, j);   // lane j now holds the half-wave total of value j = 8q + 2r + s, i.e. gsm[(col0 + 8q + r) * 2 + s]
+    atomicAdd(&gsm[col0 * 2 + 16 * (j >> 3) + (j & 7)], L[0]);
   } else {
   // (B) registers -> (+bias, +residual) -> bf16 -> LDS tile; statistics accumulate in-lane over the 4 fragments
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int p = (8 * wm + 2 * i + (j >> 4)) * 16 + (j & 15);
+  for (int i = 0; i < PXF; ++i) {
+    const int p = (2 * PXF * wm + 2 * i + (j >> 4)) * 16 + (j & 15);
     const bool inb = (oy0 + (p >> 4) < a.Ho) && (ox0 + (p & 15) < a.Wo);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -668,6 +691,31 @@ __global__ __launch_bounds__(256, 2) void conv_mfma2_kernel(ConvArgs a) {
     }
   }
   }
+  if (do_stats) {
+    // fold the 32 pixel-lanes of each wave half (fold32), then LDS atomics: one lane per (channel quad, sum)
+    float* sstat = reinterpret_cast<float*>(smem + C::STAT_OFF);   // zeroed before the main loop
+    if (ocpg >= 4) {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { v[2 * q] = st1[q]; v[2 * q + 1] = st2[q]; }
+      fold32<8>(v, j);
+      if ((j & 3) == 0) {
+        const int idx = j >> 2, q = idx >> 1;
+        const int g = (ct * CT + col0 + 8 * q) / ocpg;
+        atomicAdd(&sstat[2 * g + (idx & 1)], v[0]);
+      }
+    } else {   // two channels per group: every quad spans two groups
+      float v[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { v[4 * q] = st1[q]; v[4 * q + 1] = st2[q]; v[4 * q + 2] = su1[q]; v[4 * q + 3] = su2[q]; }
+      fold32<16>(v, j);
+      if ((j & 1) == 0) {
+        const int idx = j >> 1, q = idx >> 2;
+        const int g = (ct * CT + col0 + 8 * q) / 2;
+        atomicAdd(&sstat[2 * g + (idx & 3)], v[0]);
+      }
+    }
+  }
   __syncthreads();
   // (C) LDS tile -> global, 16 bytes per lane, consecutive lanes on consecutive addresses
 #pragma unroll
@@ -678,65 +726,37 @@ __global__ __launch_bounds__(256, 2) void conv_mfma2_kernel(ConvArgs a) {
       *(u32x4*)(a.y + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.Cout + ct * CT + epc * 8) =
           *(const u32x4*)(etile + p * C::EPITCH + epc * 16);
   }
-  if (do_stats) {
-    // fold the 32 pixel-lanes of each half wave, then one atomic per (wave, group) straight to global
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) {
-        st1[q] += __shfl_xor(st1[q], o, 64);
-        st2[q] += __shfl_xor(st2[q], o, 64);
-        if (ocpg < 4) {
-          su1[q] += __shfl_xor(su1[q], o, 64);
-          su2[q] += __shfl_xor(su2[q], o, 64);
-        }
-      }
-    }
-    float* sstat = reinterpret_cast<float*>(smem + C::STAT_OFF);   // zeroed before the main loop
-    if (j == 0) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int co = ct * CT + col0 + 8 * q;
-        if (ocpg >= 4) {
-          const int g = co / ocpg;
-          atomicAdd(&sstat[2 * g], st1[q]);
-          atomicAdd(&sstat[2 * g + 1], st2[q]);
-        } else {
-          const int g = co / 2;
-          atomicAdd(&sstat[2 * g], st1[q]);
-          atomicAdd(&sstat[2 * g + 1], st2[q]);
-          atomicAdd(&sstat[2 * g + 2], su1[q]);
-          atomicAdd(&sstat[2 * g + 3], su2[q]);
-        }
-      }
-    }
-    __syncthreads();
+  if (a.gn_mode) {
+    if (tid < 2 * CT)
+      atomicAdd(&a.g_sums[((size_t)n * a.Cout + ct * CT) * 2 + tid], reinterpret_cast<float*>(smem + C::STAT_OFF)[tid]);
+  } else if (do_stats) {
+    const float* sstat = reinterpret_cast<const float*>(smem + C::STAT_OFF);
     const int g0 = (ct * CT) / ocpg, ng = CT / ocpg;   // one wave-instruction of global atomics per workgroup
     if (tid < 2 * ng) atomicAdd(&a.out_stats[(n * a.out_groups + g0) * 2 + tid], sstat[2 * g0 + tid]);
   }
 }
 
-template <int KS, int CK, int CT>
+template <int KS, int CK, int CT, int PXF>
 int launch2_cfg(ConvArgs a, hipStream_t st) {
-  using C = Cfg2<KS, CK, CT>;
+  using C = Cfg2<KS, CK, CT, PXF>;
   a.tiles_x = cdiv(a.Wo, C::TW2);
   a.tiles_y = cdiv(a.Ho, C::TH2);
   dim3 grid(a.N * a.tiles_x * a.tiles_y, a.Cout / CT);
-  hipLaunchKernelGGL((conv_mfma2_kernel<KS, CK, CT>), grid, dim3(256), 0, st, a);
+  hipLaunchKernelGGL((conv_mfma2_kernel<KS, CK, CT, PXF>), grid, dim3(256), 0, st, a);
   return 0;
 }
 template <int KS>
 int launch2(const ConvArgs& a, int ck, int ct, hipStream_t st) {
   if (ct == 128) {
-    if (ck == 128) return launch2_cfg<KS, 128, 128>(a, st);
-    if (ck == 64) return launch2_cfg<KS, 64, 128>(a, st);
-    return launch2_cfg<KS, 32, 128>(a, st);
+    if (ck == 128) return launch2_cfg<KS, 128, 128, 4>(a, st);
+    if (ck == 64) return launch2_cfg<KS, 64, 128, 4>(a, st);
+    return launch2_cfg<KS, 32, 128, 4>(a, st);
   }
   if (ct == 64) {
-    if (ck == 64) return launch2_cfg<KS, 64, 64>(a, st);
-    return launch2_cfg<KS, 32, 64>(a, st);
+    if (ck == 64) return launch2_cfg<KS, 64, 64, 2>(a, st);
+    return launch2_cfg<KS, 32, 64, 2>(a, st);
   }
-  return launch2_cfg<KS, 32, 32>(a, st);
+  return launch2_cfg<KS, 32, 32, 2>(a, st);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -135,7 +135,7 @@ def _conv_kernel_name(ksize, mode, cin, cout):
     ck = 128 if cin % 128 == 0 else (64 if cin % 64 == 0 else 32)
     if mode == PTI_CONV_S2PAD:
         return f"conv_mfma_kernel<3, 2, {min(ck, 64)}, {ct}>"
-    return f"conv_mfma2_kernel<{ksize}, {min(ck, ct)}, {ct}>"
+    return f"conv_mfma2_kernel<{ksize}, {min(ck, ct)}, {ct}, {4 if ct == 128 else 2}>"
 
 
 # Set to a list to make conv_mfma record (kernel name, algorithmic flops, bytes, start, end events) per
