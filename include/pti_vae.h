@@ -99,6 +99,13 @@ int pti_conv2d_mfma(const void* x, const void* w_packed, const float* bias, cons
                     const float* gamma, const float* beta, const void* residual, void* y,
                     float* out_stats, const pti_conv_desc* d, pti_stream_t s);
 
+/* Same launch, plus a side output: act_out = prologue(x) as bf16 NHWC [n][h][w][cin] (the tensor autograd
+ * would save for nn.Conv2d's weight gradient).  PTI_CONV_S1 with a GroupNorm(+SiLU) prologue only.  The
+ * weight-gradient call then reads act_out with PTI_PRO_NONE instead of re-applying the prologue. */
+int pti_conv2d_mfma_saveact(const void* x, const void* w_packed, const float* bias, const float* in_stats,
+                            const float* gamma, const float* beta, const void* residual, void* y,
+                            float* out_stats, void* act_out, const pti_conv_desc* d, pti_stream_t s);
+
 /* Direct (VALU, fp32 math) convolution for the degenerate-channel layers (cin or cout < 32):
  * conv_in, conv_out of Encoder/Decoder.  w: fp32 [k*k][cin][cout]; see pti_conv_desc strides. */
 int pti_conv2d_direct(const void* x, const float* w_tck, const float* bias, const float* in_stats,

@@ -45,6 +45,7 @@ SIGNATURES = {
     "pti_conv_pack_weights_batched": (_I, [_P, _P, _I, _I, _P]),
     "pti_gn_stats": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "pti_conv2d_mfma": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(ConvDesc), _P]),
+    "pti_conv2d_mfma_saveact": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(ConvDesc), _P]),
     "pti_conv2d_direct": (_I, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(ConvDesc), _P]),
     "pti_wgrad_direct": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I,
                               C.POINTER(_I64), _I64, _I64, _I64, _P, _I64, _P]),

@@ -78,6 +78,9 @@ struct ConvArgs {
   float g_inv_cnt, g_eps;
   const float* g_stats; const float* g_gamma; const float* g_beta;
   float* g_sums;
+  // optional side output (v2 kernel, PTI_CONV_S1 with a prologue): the activated input act(GN(x)) as bf16 NHWC,
+  // written by the cout-tile-0 workgroups from their staging registers, for the weight-gradient pass to reuse
+  bf16* act_out;
 };
 
 template <int KS, int S, int CK, int COUT_TILE>
@@ -518,6 +521,11 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
             f[j] = v;
           }
           r = pack8(f);
+          if (a.act_out && ct == 0) {   // interior pixels of this tile only (halo pixels belong to the neighbours)
+            constexpr int PL = (KS - 1) / 2;
+            if (hy >= PL && hy < PL + C::TH2 && hx >= PL && hx < PL + C::TW2)
+              *(u32x4*)(a.act_out + ((size_t)(n * a.H + vy0 + hy) * a.W + vx0 + hx) * a.Cin + chunk * CK + lc * 8) = r;
+          }
         }
         const int key = (hx >> C::KEY_SHIFT) & (C::NC - 1);
         *(u32x4*)(halo + p * C::PIXB + ((lc ^ key) << 4)) = r;
@@ -914,8 +922,11 @@ struct GnBwdFuse { int mode; const float* stats; const float* gamma; const float
 
 static int conv2d_mfma_impl(const void* x, const void* w_packed, const float* bias, const float* in_stats,
                             const float* gamma, const float* beta, const void* residual, void* y,
-                            float* out_stats, const pti_conv_desc* d, const GnBwdFuse* gf, pti_stream_t s) {
+                            float* out_stats, const pti_conv_desc* d, const GnBwdFuse* gf, void* act_out,
+                            pti_stream_t s) {
   if (!x || !w_packed || !y || !d) PTI_FAIL(PTI_EINVAL, "conv2d_mfma: null pointer");
+  if (act_out && (d->mode != PTI_CONV_S1 || d->prologue == PTI_PRO_NONE))
+    PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: the activated-input side output needs PTI_CONV_S1 and a GroupNorm prologue");
   if (d->cin % 32 || d->cout % 32 || d->cin <= 0 || d->cout <= 0)
     PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: cin=%d cout=%d must be positive multiples of 32", d->cin, d->cout);
   if (d->ksize != 1 && d->ksize != 3) PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: ksize %d", d->ksize);
@@ -950,6 +961,7 @@ static int conv2d_mfma_impl(const void* x, const void* w_packed, const float* bi
   a.mode = d->mode; a.prologue = d->prologue; a.groups = d->groups; a.out_groups = d->out_groups;
   a.gn_mode = 0; a.g_groups = 0; a.g_inv_cnt = 0.f; a.g_eps = 0.f;
   a.g_stats = a.g_gamma = a.g_beta = nullptr; a.g_sums = nullptr;
+  a.act_out = (bf16*)act_out;
   a.eps = d->eps;
   a.inv_cnt = d->prologue != PTI_PRO_NONE ? 1.0f / ((float)(d->cin / d->groups) * (float)d->h * (float)d->w) : 0.f;
   if (gf) {
@@ -975,7 +987,14 @@ static int conv2d_mfma_impl(const void* x, const void* w_packed, const float* bi
 extern "C" int pti_conv2d_mfma(const void* x, const void* w_packed, const float* bias, const float* in_stats,
                                const float* gamma, const float* beta, const void* residual, void* y,
                                float* out_stats, const pti_conv_desc* d, pti_stream_t s) {
-  return conv2d_mfma_impl(x, w_packed, bias, in_stats, gamma, beta, residual, y, out_stats, d, nullptr, s);
+  return conv2d_mfma_impl(x, w_packed, bias, in_stats, gamma, beta, residual, y, out_stats, d, nullptr, nullptr, s);
+}
+
+extern "C" int pti_conv2d_mfma_saveact(const void* x, const void* w_packed, const float* bias, const float* in_stats,
+                                       const float* gamma, const float* beta, const void* residual, void* y,
+                                       float* out_stats, void* act_out, const pti_conv_desc* d, pti_stream_t s) {
+  if (!act_out) PTI_FAIL(PTI_EINVAL, "conv2d_mfma_saveact: null act_out");
+  return conv2d_mfma_impl(x, w_packed, bias, in_stats, gamma, beta, residual, y, out_stats, d, nullptr, act_out, s);
 }
 
 extern "C" int pti_conv2d_mfma_gnbwd(const void* dy_in, const void* w_packed, const void* gx, const float* gstats,
@@ -988,5 +1007,5 @@ extern "C" int pti_conv2d_mfma_gnbwd(const void* dy_in, const void* w_packed, co
   GnBwdFuse gf{silu ? 2 : 1, gstats, ggamma, gbeta, gsums};
   pti_conv_desc dd = *d;
   dd.add_residual = 1;   // the GN input rides the residual path into LDS
-  return conv2d_mfma_impl(dy_in, w_packed, nullptr, nullptr, nullptr, nullptr, gx, dy_out, nullptr, &dd, &gf, s);
+  return conv2d_mfma_impl(dy_in, w_packed, nullptr, nullptr, nullptr, nullptr, gx, dy_out, nullptr, &dd, &gf, nullptr, s);
 }

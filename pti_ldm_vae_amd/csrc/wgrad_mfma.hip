@@ -280,8 +280,22 @@ __global__ __launch_bounds__(192) void wgrad_mfma3_kernel(WgArgs a) {
   unsigned char* lA = smem;
   unsigned char* lD = smem + C::A_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, kh = tid >> 6;
-  const int split = blockIdx.y;
-  const int cot = blockIdx.x / a.ci_tiles, cit = blockIdx.x % a.ci_tiles;
+  // XCD-aware block order: consecutive workgroup ids go round-robin over the 8 XCDs (one L2 each), so the
+  // (co, ci) blocks that stream the SAME pixel tiles (same split) are placed on the same XCD, back to back:
+  // id = 8 * (tiles_cc * (split / 8) + cc) + split % 8.  Host guarantees S % 8 == 0 or S < 8 (then id = S * cc + split).
+  int split, cc;
+  {
+    const int id = blockIdx.x, tiles_cc = a.ci_tiles * (a.Cout / 32);
+    if (a.S >= 8) {
+      const int k = id >> 3;
+      cc = k % tiles_cc;
+      split = (k / tiles_cc) * 8 + (id & 7);
+    } else {
+      cc = id / a.S;
+      split = id % a.S;
+    }
+  }
+  const int cot = cc / a.ci_tiles, cit = cc % a.ci_tiles;
   const bool twox = (a.mode == PTI_CONV_UP2);
   const int VH = twox ? 2 * a.H : a.H, VW = twox ? 2 * a.W : a.W;
 
@@ -535,8 +549,9 @@ extern "C" int pti_conv_wgrad_mfma(const void* x, const void* dy, const float* i
     if (S3 > 512) S3 = 512;
     if (S3 < 1) S3 = 1;
     if (S3 > smax) S3 = (int)smax;
+    if (S3 >= 8) S3 &= ~7;   // whole rounds over the 8 XCDs (see the block-order note in the kernel)
     a.S = S = S3;
-    hipLaunchKernelGGL(wgrad_mfma3_kernel, dim3(tiles_cc, S3), dim3(192), 0, st, a);
+    hipLaunchKernelGGL(wgrad_mfma3_kernel, dim3(tiles_cc * S3), dim3(192), 0, st, a);
   } else if (d->ksize == 1) launch_wt<1, 1>(a, co_t, ci_t, tiles_cc, st);
   else if (d->mode == PTI_CONV_S2PAD) launch_wt<3, 2>(a, co_t, ci_t, tiles_cc, st);
   else launch_wt<3, 1>(a, co_t, ci_t, tiles_cc, st);

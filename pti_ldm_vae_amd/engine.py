@@ -14,6 +14,8 @@ flat gradient arena and hand autograd views of it.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops
@@ -79,7 +81,7 @@ class _MfmaConv:
         self.wpt = ops.pack_conv_weight(w, self.ksize, dmode, flip=True, out=self.wpt)
 
     # y = conv(prologue(x)) + b [+ residual]; optional fused stats of y
-    def fwd(self, x, *, pro=PTI_PRO_NONE, norm=None, residual=None, want_stats=False, eng=None):
+    def fwd(self, x, *, pro=PTI_PRO_NONE, norm=None, residual=None, want_stats=False, eng=None, act_out=None):
         n, h, w, _ = x.t.shape
         ho, wo = ops.conv_out_hw(h, w, self.mode)
         y = _empty((n, ho, wo, self.cout), x.t)
@@ -87,7 +89,7 @@ class _MfmaConv:
         g, b = (norm.weight.data, norm.bias.data) if norm is not None else (None, None)
         ops.conv_mfma(x.t, self.wp, self.bias(), y, cout=self.cout, ksize=self.ksize, mode=self.mode, prologue=pro,
                       in_stats=x.stats if pro else None, gamma=g, beta=b, groups=eng.G, eps=eng.eps,
-                      residual=residual, out_stats=st, out_groups=eng.G)
+                      residual=residual, out_stats=st, out_groups=eng.G, act_out=act_out)
         return _Act(y, st)
 
     # data gradient w.r.t. the (post-prologue) input
@@ -156,18 +158,32 @@ class _ResBlock:
         self.prefix = p + "."
 
     def fwd(self, x, eng, want_stats, save):
-        h1 = self.conv1.fwd(x, pro=PTI_PRO_GN_SILU, norm=self.norm1, want_stats=True, eng=eng)
+        # training: the convs also write their activated inputs SiLU(GN(.)) (what autograd saves for the weight
+        # gradient), so that the weight-gradient kernels do not redo the normalisation + SiLU on every halo tile
+        a1 = a2 = None
+        if save is not None and eng.saves_activated_input(x.t):
+            a1 = _empty(x.t.shape, x.t)
+        h1 = self.conv1.fwd(x, pro=PTI_PRO_GN_SILU, norm=self.norm1, want_stats=True, eng=eng, act_out=a1)
         sc = x.t if self.nin is None else self.nin.fwd(x, eng=eng).t
-        out = self.conv2.fwd(h1, pro=PTI_PRO_GN_SILU, norm=self.norm2, residual=sc, want_stats=want_stats, eng=eng)
+        if save is not None and eng.saves_activated_input(h1.t):
+            a2 = _empty(h1.t.shape, h1.t)
+        out = self.conv2.fwd(h1, pro=PTI_PRO_GN_SILU, norm=self.norm2, residual=sc, want_stats=want_stats, eng=eng,
+                             act_out=a2)
         if save is not None:
-            save.append((x, h1))
+            save.append((x, h1, a1, a2))
         return out
 
     def bwd(self, dout, saved, eng):
-        x, h1 = saved
-        self.conv2.wgrad(h1, dout, pro=PTI_PRO_GN_SILU, norm=self.norm2, eng=eng)
+        x, h1, a1, a2 = saved
+        if a2 is not None:
+            self.conv2.wgrad(_Act(a2), dout, eng=eng)
+        else:
+            self.conv2.wgrad(h1, dout, pro=PTI_PRO_GN_SILU, norm=self.norm2, eng=eng)
         dh1 = self.conv2.dgrad_gn(dout, h1, self.norm2, silu=True, dres=None, eng=eng)
-        self.conv1.wgrad(x, dh1, pro=PTI_PRO_GN_SILU, norm=self.norm1, eng=eng)
+        if a1 is not None:
+            self.conv1.wgrad(_Act(a1), dh1, eng=eng)
+        else:
+            self.conv1.wgrad(x, dh1, pro=PTI_PRO_GN_SILU, norm=self.norm1, eng=eng)
         if self.nin is None:
             dres = dout
         else:
@@ -280,6 +296,7 @@ class Engine:
         self._range_cache = {}
         self._zpool, self._zoff, self._zpool_size = None, 0, 1 << 16
         self._packer = None
+        self.save_act_min_hw = int(os.environ.get("PTI_SAVE_ACT_MIN_HW", "0"))
         ops.L.lib()  # fail loudly now if the HIP extension is missing
         for c in net.channels:
             if c % 32:
@@ -308,6 +325,12 @@ class Engine:
         self.direct_convs = [self.enc_in, self.enc_out, self.dec_in, self.dec_out]
         self.Lc = net.latent_channels
         self._plist = list(net._param_by_name.values())
+
+    def saves_activated_input(self, t) -> bool:
+        """Whether a ResBlock conv on input ``t`` (NHWC) also writes SiLU(GN(t)) for its weight-gradient pass.
+        Pays where the weight gradient is bound by the prologue's VALU work (large maps); costs one extra bf16
+        copy of ``t`` kept until backward.  PTI_SAVE_ACT_MIN_HW overrides the pixel threshold (0 = always)."""
+        return t.shape[1] * t.shape[2] >= self.save_act_min_hw
 
     def _make_layer(self, blk, prefix):
         if isinstance(blk, M.AEKLResBlock):

@@ -82,10 +82,15 @@ def gn_stats(x, groups, stats=None):
 
 
 def conv_mfma(x, w_packed, bias, y, *, cout, ksize=3, mode=PTI_CONV_S1, prologue=PTI_PRO_NONE, in_stats=None,
-              gamma=None, beta=None, groups=0, eps=1e-6, residual=None, out_stats=None, out_groups=0):
+              gamma=None, beta=None, groups=0, eps=1e-6, residual=None, out_stats=None, out_groups=0, act_out=None):
+    """``act_out`` (optional, bf16, x's shape): also write prologue(x) for the weight-gradient pass to reuse."""
     _chk(x, BF16, "x", 4)
     _chk(y, BF16, "y", 4)
     n, h, w, cin = x.shape
+    if act_out is not None:
+        _chk(act_out, BF16, "act_out", 4)
+        if act_out.shape != x.shape:
+            raise ValueError("conv_mfma: act_out shape")
     ho, wo = conv_out_hw(h, w, mode)
     if tuple(y.shape) != (n, ho, wo, cout):
         raise ValueError(f"conv_mfma: y shape {tuple(y.shape)} != {(n, ho, wo, cout)}")
@@ -115,16 +120,21 @@ def conv_mfma(x, w_packed, bias, y, *, cout, ksize=3, mode=PTI_CONV_S1, prologue
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    L.check(L.lib().pti_conv2d_mfma(_ptr(x), _ptr(w_packed), _ptr(bias), _ptr(in_stats), _ptr(gamma), _ptr(beta),
-                                    _ptr(residual), _ptr(y), _ptr(out_stats), C.byref(d), _stream()),
-            "pti_conv2d_mfma")
+    if act_out is not None:
+        L.check(L.lib().pti_conv2d_mfma_saveact(_ptr(x), _ptr(w_packed), _ptr(bias), _ptr(in_stats), _ptr(gamma),
+                                                _ptr(beta), _ptr(residual), _ptr(y), _ptr(out_stats), _ptr(act_out),
+                                                C.byref(d), _stream()), "pti_conv2d_mfma_saveact")
+    else:
+        L.check(L.lib().pti_conv2d_mfma(_ptr(x), _ptr(w_packed), _ptr(bias), _ptr(in_stats), _ptr(gamma), _ptr(beta),
+                                        _ptr(residual), _ptr(y), _ptr(out_stats), C.byref(d), _stream()),
+                "pti_conv2d_mfma")
     if prof is not None:
         e1.record()
         name = _conv_kernel_name(ksize, mode, cin, cout)
         # algorithmic work; the zero-insert data gradient only has 1/4 useful taps per output pixel
         flops = 2.0 * n * ho * wo * cout * cin * ksize * ksize * (0.25 if mode == PTI_CONV_ZINS else 1.0)
         # algorithmic bytes: read the input once (bf16), write the output once (+ residual read)
-        nbytes = 2.0 * (x.numel() + y.numel() * (2 if residual is not None else 1))
+        nbytes = 2.0 * (x.numel() * (2 if act_out is not None else 1) + y.numel() * (2 if residual is not None else 1))
         prof.append((name, flops, nbytes, e0, e1))
     return y
 

@@ -130,12 +130,16 @@ def test_conv_mfma(dev, n, cin, cout, h, w, ks, mode, pro, res, ostats):
     st = ops.gn_stats(xd, groups) if pro else None
     og = 16
     ost = torch.zeros(n, og, 2, device=dev) if ostats else None
+    # S1 + prologue launches also exercise the side output act_out = prologue(x) (pti_conv2d_mfma_saveact)
+    act = torch.full_like(xd, float("nan")) if (pro and mode == "s1") else None
     ops.conv_mfma(xd, wp, bias.to(dev), y, cout=cout, ksize=ks, mode=m, prologue=pro, in_stats=st,
                   gamma=gamma.to(dev) if pro else None, beta=beta.to(dev) if pro else None, groups=groups, eps=eps,
-                  residual=_nhwc(rs).to(dev, torch.bfloat16) if res else None, out_stats=ost, out_groups=og)
+                  residual=_nhwc(rs).to(dev, torch.bfloat16) if res else None, out_stats=ost, out_groups=og, act_out=act)
     torch.cuda.synchronize()
     got = y.float().cpu().permute(0, 3, 1, 2)
     _report(f"conv_mfma[{mode},k{ks},{cin}->{cout},pro{pro}]", got, ref)
+    if act is not None:   # bf16 of an fp32 GN+SiLU: one rounding step of slack against the CPU reference
+        _report("conv_mfma act_out", act.float().cpu().permute(0, 3, 1, 2), a, max_frac=1e-2, l2=3e-3)
     if ostats:
         _report("conv_mfma fused stats", ost, _stats_ref(_r(got), og), max_frac=1e-3, l2=1e-4)
 
