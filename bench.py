@@ -12,9 +12,11 @@ Inputs are resident in HBM before the timed region.  For N>1 launch with
 ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...``.
 
 Prints ONE JSON line (rank 0): metric/value/unit/..., plus
-  "roofline":     dominant kernel (by time) among the MFMA conv kernels, timed with events on the launch
-                  stream during extra instrumented steps right after the timed region (so the headline
-                  number is not perturbed); achieved = algorithmic FLOP per launch / avg launch duration.
+  "roofline":     dominant kernel (by time) among the MFMA conv / weight-gradient kernels, timed with events on
+                  the launch stream during extra instrumented steps right after the timed region (so the
+                  headline number is not perturbed); the bound ("hbm" or "mfma") follows the kernel's
+                  algorithmic flop/byte against the machine balance; achieved = algorithmic bytes (or FLOP)
+                  per launch / average launch duration.
   "cpu_baseline": the CPU fp32 oracle's training step (oracle/, kind "port") on the host cores.
 """
 from __future__ import annotations
@@ -31,7 +33,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0   # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
-PEAK_HBM_GBS = 8000.0
+PEAK_HBM_GBS = 8000.0       # HBM3E spec, same guide (~6.3 TB/s is what a streaming kernel reaches)
+PMC_TRAFFIC_FILE = "r01_pmc_traffic.json"   # tools/pmc_traffic.py output of the two --pmc passes
 TRAIN_GFLOP_PER_IMG_A = 148.11   # BASELINE.md §3 (config A, 256x256, 1 channel; fwd 49.37 x 3)
 
 
@@ -144,7 +147,7 @@ def main():
     loss = float(out["loss"].item())
     log(f"timed region {dt:.3f}s, loss {loss:.5f}; instrumented steps")
 
-    # ---- instrumented steps: per-launch event timing of the MFMA conv kernels (rank 0) ----
+    # ---- instrumented steps: per-launch event timing of the MFMA conv + weight-gradient kernels (rank 0) ----
     roofline = None
     if rank == 0:
         ops.KERNEL_PROFILE = []
@@ -162,23 +165,31 @@ def main():
             a[3] += 1
         if agg:
             name, (tsec, flops, nbytes, cnt) = max(agg.items(), key=lambda kv: kv[1][0])
-            ach = flops / tsec / 1e12
+            # which roof bounds the dominant kernel: its algorithmic intensity against the machine balance
+            intensity = flops / nbytes
+            hbm_bound = intensity < PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+            tfl, gbs = flops / tsec / 1e12, nbytes / tsec / 1e9
             traffic = None   # HBM bytes per launch from the separate rocprofv3 --pmc passes committed under profiles/
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"].get(name)
+                pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)))["kernels"].get(name)
                 if pmc:
                     traffic = pmc["fetch_bytes"] + pmc["write_bytes"]
             except (OSError, ValueError, KeyError):
                 pass
-            roofline = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                        "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, avg per launch)",
+            roofline = {"kernel": name, "bound": "hbm" if hbm_bound else "mfma",
+                        "achieved": round(gbs if hbm_bound else tfl, 2),
+                        "peak": PEAK_HBM_GBS if hbm_bound else PEAK_BF16_TFLOPS,
+                        "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                        "frac": round(gbs / PEAK_HBM_GBS if hbm_bound else tfl / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                        "traffic_source": f"profiles/{PMC_TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, avg per launch)",
                         "algorithmic_bytes_per_launch": round(nbytes / cnt),
-                        "launches_per_step": cnt // 2, "avg_launch_us": round(tsec / cnt * 1e6, 2),
                         "algorithmic_gflop_per_launch": round(flops / cnt / 1e9, 3),
-                        "algorithmic_hbm_gbs": round(nbytes / tsec / 1e9, 1),
-                        "all_conv_kernels": {k: {"ms_per_step": round(v[0] / 2 * 1e3, 3),
-                                                 "tflops": round(v[1] / v[0] / 1e12, 1), "launches": v[3] // 2}
+                        "flop_per_byte": round(intensity, 1),
+                        "launches_per_step": cnt // 2, "avg_launch_us": round(tsec / cnt * 1e6, 2),
+                        "algorithmic_tflops": round(tfl, 1), "algorithmic_hbm_gbs": round(gbs, 1),
+                        "all_mfma_kernels": {k: {"ms_per_step": round(v[0] / 2 * 1e3, 3),
+                                                 "tflops": round(v[1] / v[0] / 1e12, 1),
+                                                 "gbs": round(v[2] / v[0] / 1e9), "launches": v[3] // 2}
                                              for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}}
     if world > 1:
         dist.barrier()

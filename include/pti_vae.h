@@ -100,7 +100,7 @@ int pti_conv2d_mfma(const void* x, const void* w_packed, const float* bias, cons
                     float* out_stats, const pti_conv_desc* d, pti_stream_t s);
 
 /* Same launch, plus a side output: act_out = prologue(x) as bf16 NHWC [n][h][w][cin] (the tensor autograd
- * would save for nn.Conv2d's weight gradient).  PTI_CONV_S1 with a GroupNorm(+SiLU) prologue only.  The
+ * would save for nn.Conv2d's weight gradient).  3x3 PTI_CONV_S1 with a GroupNorm(+SiLU) prologue only.  The
  * weight-gradient call then reads act_out with PTI_PRO_NONE instead of re-applying the prologue. */
 int pti_conv2d_mfma_saveact(const void* x, const void* w_packed, const float* bias, const float* in_stats,
                             const float* gamma, const float* beta, const void* residual, void* y,
@@ -134,6 +134,15 @@ int pti_conv_wgrad_mfma(const void* x, const void* dy, const float* in_stats, co
                         const float* beta, float* dw, float* dbias, void* workspace,
                         int64_t workspace_bytes, int accumulate, const pti_conv_desc* d,
                         pti_stream_t s);
+/* The same work as two calls (pti_conv_wgrad_mfma is exactly partials + reduce): the split-K partial launch,
+ * which reports the number of slabs it wrote, and the fixed-order slab reduction into dw / dbias.  Lets a
+ * caller time or overlap the two launches separately. */
+int pti_conv_wgrad_mfma_partials(const void* x, const void* dy, const float* in_stats,
+                                 const float* gamma, const float* beta, void* workspace,
+                                 int64_t workspace_bytes, const pti_conv_desc* d, int* splits_out,
+                                 pti_stream_t s);
+int pti_conv_wgrad_reduce(const void* workspace, int splits, float* dw, float* dbias,
+                          int accumulate, const pti_conv_desc* d, pti_stream_t s);
 
 /* ---- GroupNorm(+SiLU) backward, 2x2 sum pool ---------------------------------------------- */
 /* dx = d/dx of act(GroupNorm(x)) given da (+ dres added), dgamma/dbeta += ; sums: zeroed float

@@ -51,6 +51,8 @@ SIGNATURES = {
                               C.POINTER(_I64), _I64, _I64, _I64, _P, _I64, _P]),
     "pti_conv_wgrad_workspace_bytes": (_I64, [_I, _I, _I, _I]),
     "pti_conv_wgrad_mfma": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I, C.POINTER(ConvDesc), _P]),
+    "pti_conv_wgrad_mfma_partials": (_I, [_P, _P, _P, _P, _P, _P, _I64, C.POINTER(ConvDesc), C.POINTER(_I), _P]),
+    "pti_conv_wgrad_reduce": (_I, [_P, _I, _P, _P, _I, C.POINTER(ConvDesc), _P]),
     "pti_gn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
     "pti_conv2d_mfma_gnbwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(ConvDesc), _I, _P]),
     "pti_gn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),

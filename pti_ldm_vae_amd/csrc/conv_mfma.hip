@@ -346,6 +346,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
 // the 32/64-channel tiles: those layers are HBM-latency-bound, and halving the accumulators + a 3-deep weight
 // ring fits 4 workgroups/CU (128 VGPRs) -- measured 32->32@256^2 100.6 -> 81.4 us, 64->32 159 -> 133 us.
 // (tried: PXF = 1 -> more weight traffic per MFMA and 1.4-1.7x halo amplification, 1.5x slower.)
+// 128-channel tile (128->128 @64^2, batch 32: ~46-50 us, ~800 TF/s), what was measured:
+//  * no global halo loads and no stores: 35 us; also no weight loads / LDS reads in the loop: 30 us (MFMA skeleton);
+//    staging + epilogue alone (no MFMA loop): 21 us.  The memory phases are NOT hidden behind the MFMA loop: a
+//    launch is only 2 rounds of 2 workgroups/CU and every workgroup is in the same phase at the same time.
+//  * 1-row x 32-pixel fragments shared across the 3 kernel rows (-40 % LDS reads): no gain (LDS ~21 % busy).
+//  * PXF = 2 at 3-4 workgroups/CU, weight ring 3/6/9 deep: all within +-3 %.  A start delay for every other
+//    workgroup: slower.  Next: persistent workgroups with cross-tile halo prefetch.
 // =============================================================================================
 __host__ __device__ constexpr int pick_ck2(int cin, int ct) {
   const int ck = cin % 128 == 0 ? 128 : (cin % 64 == 0 ? 64 : 32);
@@ -406,7 +413,7 @@ struct Cfg2 {
   static constexpr int LDS_BYTES = STAT_OFF + 1024;
 };
 
-template <int KS, int CK, int CT, int PXF>
+template <int KS, int CK, int CT, int PXF, bool SAVE>
 __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(ConvArgs a) {
   using C = Cfg2<KS, CK, CT, PXF>;
   __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS_BYTES];
@@ -471,7 +478,7 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
         dst[u] = *(const bf16x8*)(wlane + (size_t)kb * C::NT * 1024);
       }
     };
-    wload(wa, 0);
+    if constexpr (!(SAVE && PXF == 2)) wload(wa, 0);   // (side-output variant at the 128-VGPR cap: after staging)
 
     float sc[8], sh[8];
     if (a.prologue != PTI_PRO_NONE) {
@@ -521,11 +528,6 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
             f[j] = v;
           }
           r = pack8(f);
-          if (a.act_out && ct == 0) {   // interior pixels of this tile only (halo pixels belong to the neighbours)
-            constexpr int PL = (KS - 1) / 2;
-            if (hy >= PL && hy < PL + C::TH2 && hx >= PL && hx < PL + C::TW2)
-              *(u32x4*)(a.act_out + ((size_t)(n * a.H + vy0 + hy) * a.W + vx0 + hx) * a.Cin + chunk * CK + lc * 8) = r;
-          }
         }
         const int key = (hx >> C::KEY_SHIFT) & (C::NC - 1);
         *(u32x4*)(halo + p * C::PIXB + ((lc ^ key) << 4)) = r;
@@ -533,6 +535,29 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
     }
     __syncthreads();
 
+    if constexpr (SAVE) {
+      // side output act(GN(x)): copied out of the staged tile (interior pixels only; halo pixels belong to the
+      // neighbouring tiles) rather than stored from the staging registers -- that kept addresses live across the
+      // staging loop and spilled ~17 VGPRs at the 128-register cap (+300 MB of scratch traffic per launch)
+      if (ct == 0) {
+        constexpr int PL = (KS - 1) / 2;
+        constexpr int SITERS = C::TH2 * C::TW2 * C::NC / 256;
+#pragma unroll 1
+        for (int it = 0; it < SITERS; ++it) {
+          const int idx = tid + it * 256;
+          const int c8 = idx % C::NC, pi = idx / C::NC;
+          const int hy = pi / C::TW2 + PL, hx = pi % C::TW2 + PL;
+          const int vy = vy0 + hy, vx = vx0 + hx;
+          if (vy < a.H && vx < a.W) {
+            const int key = (hx >> C::KEY_SHIFT) & (C::NC - 1);
+            *(u32x4*)(a.act_out + ((size_t)(n * a.H + vy) * a.W + vx) * a.Cin + chunk * CK + c8 * 8) =
+                *(const u32x4*)(halo + (hy * C::HW + hx) * C::PIXB + ((c8 ^ key) << 4));
+          }
+        }
+      }
+    }
+
+    if constexpr (SAVE && PXF == 2) wload(wa, 0);
     // main loop over groups of R k-blocks.  B (pixel) fragments are double-buffered in registers: the 4
     // ds_read_b128 of k-block u+1 are issued before the 4 MFMAs of k-block u.
     const int txl = lane & 15;
@@ -750,7 +775,15 @@ int launch2_cfg(ConvArgs a, hipStream_t st) {
   a.tiles_x = cdiv(a.Wo, C::TW2);
   a.tiles_y = cdiv(a.Ho, C::TH2);
   dim3 grid(a.N * a.tiles_x * a.tiles_y, a.Cout / CT);
-  hipLaunchKernelGGL((conv_mfma2_kernel<KS, CK, CT, PXF>), grid, dim3(256), 0, st, a);
+  if constexpr (KS == 3) {   // the activated-input side output is a separate instantiation (3x3 only)
+    if (a.act_out) {
+      hipLaunchKernelGGL((conv_mfma2_kernel<KS, CK, CT, PXF, true>), grid, dim3(256), 0, st, a);
+      return 0;
+    }
+  } else if (a.act_out) {
+    return 1;
+  }
+  hipLaunchKernelGGL((conv_mfma2_kernel<KS, CK, CT, PXF, false>), grid, dim3(256), 0, st, a);
   return 0;
 }
 template <int KS>
@@ -925,8 +958,8 @@ static int conv2d_mfma_impl(const void* x, const void* w_packed, const float* bi
                             float* out_stats, const pti_conv_desc* d, const GnBwdFuse* gf, void* act_out,
                             pti_stream_t s) {
   if (!x || !w_packed || !y || !d) PTI_FAIL(PTI_EINVAL, "conv2d_mfma: null pointer");
-  if (act_out && (d->mode != PTI_CONV_S1 || d->prologue == PTI_PRO_NONE))
-    PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: the activated-input side output needs PTI_CONV_S1 and a GroupNorm prologue");
+  if (act_out && (d->mode != PTI_CONV_S1 || d->prologue == PTI_PRO_NONE || d->ksize != 3))
+    PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: the activated-input side output needs a 3x3 PTI_CONV_S1 launch with a GroupNorm prologue");
   if (d->cin % 32 || d->cout % 32 || d->cin <= 0 || d->cout <= 0)
     PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: cin=%d cout=%d must be positive multiples of 32", d->cin, d->cout);
   if (d->ksize != 1 && d->ksize != 3) PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: ksize %d", d->ksize);

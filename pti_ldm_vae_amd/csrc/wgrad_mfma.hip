@@ -507,15 +507,22 @@ extern "C" int64_t pti_conv_wgrad_workspace_bytes(int cout, int cin, int ksize, 
   return (int64_t)splits * ((int64_t)ksize * ksize * cout * cin + cout) * 4;
 }
 
-extern "C" int pti_conv_wgrad_mfma(const void* x, const void* dy, const float* in_stats, const float* gamma,
-                                   const float* beta, float* dw, float* dbias, void* workspace,
-                                   int64_t workspace_bytes, int accumulate, const pti_conv_desc* d, pti_stream_t s) {
-  if (!x || !dy || !dw || !workspace || !d) PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma: null pointer");
+static int wgrad_check(const void* x, const void* dy, const float* in_stats, const float* gamma, const float* beta,
+                       const void* workspace, const pti_conv_desc* d) {
+  if (!x || !dy || !workspace || !d) PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma: null pointer");
   if (d->cin % 32 || d->cout % 32) PTI_FAIL(PTI_EUNSUPPORTED, "conv_wgrad_mfma: cin=%d cout=%d", d->cin, d->cout);
   if (d->ksize != 1 && d->ksize != 3) PTI_FAIL(PTI_EUNSUPPORTED, "conv_wgrad_mfma: ksize");
   if (d->mode == PTI_CONV_ZINS || (d->ksize == 1 && d->mode != PTI_CONV_S1)) PTI_FAIL(PTI_EUNSUPPORTED, "conv_wgrad_mfma: mode %d", d->mode);
   if (d->prologue != PTI_PRO_NONE && (!in_stats || !gamma || !beta || d->groups <= 0 || d->cin % d->groups))
     PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma: prologue args");
+  return PTI_OK;
+}
+
+extern "C" int pti_conv_wgrad_mfma_partials(const void* x, const void* dy, const float* in_stats, const float* gamma,
+                                            const float* beta, void* workspace, int64_t workspace_bytes,
+                                            const pti_conv_desc* d, int* splits_out, pti_stream_t s) {
+  if (!splits_out) PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma_partials: null splits_out");
+  if (int rc = wgrad_check(x, dy, in_stats, gamma, beta, workspace, d)) return rc;
   WgArgs a;
   a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.in_stats = in_stats; a.gamma = gamma; a.beta = beta;
   a.slab = (float*)workspace;
@@ -523,42 +530,51 @@ extern "C" int pti_conv_wgrad_mfma(const void* x, const void* dy, const float* i
   a.mode = d->mode; a.prologue = d->prologue; a.groups = d->groups; a.eps = d->eps;
   a.inv_cnt = d->prologue != PTI_PRO_NONE ? 1.0f / ((float)(d->cin / d->groups) * (float)d->h * (float)d->w) : 0.f;
   a.tiles_x = cdiv(d->wo, TW); a.tiles_y = cdiv(d->ho, TH); a.ntiles = d->n * a.tiles_x * a.tiles_y;
-  // Tile / split choice: 64x64 (co,ci) tiles only when every workgroup still gets >= 16 pixel tiles at ~512
-  // workgroups; otherwise 32x32 tiles (4 waves split the pixels) so that fewer, longer splits are needed and
-  // the partial-slab traffic (S x full dW) stays small.
+  // Tile / split choice.  3x3 stride-1 gathers: the tap-split 32x32 kernel (v3, measured faster on every such
+  // shape).  Others (1x1, stride 2): 64x64 (co,ci) tiles only when every workgroup still gets >= 16 pixel tiles at
+  // ~512 workgroups, otherwise 32x32 so that fewer, longer splits keep the partial-slab traffic (S x dW) small.
   int co_t = d->cout % 64 == 0 ? 64 : 32, ci_t = d->cin % 64 == 0 ? 64 : 32;
   if ((long long)a.ntiles * (d->cout / co_t) * (d->cin / ci_t) < 16 * 512) co_t = ci_t = 32;
-  if (d->ksize == 3 && d->mode != PTI_CONV_S2PAD) co_t = ci_t = 32;   // v3 (tap-split, 32x32) measured faster on every 3x3 shape
+  const bool v3 = d->ksize == 3 && d->mode != PTI_CONV_S2PAD;
+  if (v3) co_t = ci_t = 32;
   a.ci_tiles = d->cin / ci_t;
   const int tiles_cc = (d->cout / co_t) * a.ci_tiles;
   const int kk = d->ksize * d->ksize;
   a.slab_stride = (long long)kk * d->cout * d->cin + d->cout;
-  long long smax = workspace_bytes / (a.slab_stride * 4);
-  int S = 512 / tiles_cc;
+  const long long smax = workspace_bytes / (a.slab_stride * 4);
+  int S = (v3 ? 1280 : 512) / tiles_cc;      // v3: three waves per workgroup, ~5 workgroups per CU
   if (S > a.ntiles / 4) S = a.ntiles / 4;
-  if (S > 256) S = 256;
+  if (S > (v3 ? 512 : 256)) S = v3 ? 512 : 256;
   if (S < 1) S = 1;
   if (S > smax) S = (int)smax;
   if (S < 1) PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma: workspace too small (%lld bytes per split needed)", a.slab_stride * 4);
+  if (v3 && S >= 8) S &= ~7;   // whole rounds over the 8 XCDs (see the block-order note in the kernel)
   a.S = S;
   hipStream_t st = (hipStream_t)s;
-  if (d->ksize == 3 && d->mode != PTI_CONV_S2PAD && co_t == 32 && ci_t == 32) {
-    // v3: three waves per workgroup (one per kernel row), ~5 workgroups per CU
-    int S3 = 1280 / tiles_cc;
-    if (S3 > a.ntiles / 4) S3 = a.ntiles / 4;
-    if (S3 > 512) S3 = 512;
-    if (S3 < 1) S3 = 1;
-    if (S3 > smax) S3 = (int)smax;
-    if (S3 >= 8) S3 &= ~7;   // whole rounds over the 8 XCDs (see the block-order note in the kernel)
-    a.S = S = S3;
-    hipLaunchKernelGGL(wgrad_mfma3_kernel, dim3(tiles_cc * S3), dim3(192), 0, st, a);
-  } else if (d->ksize == 1) launch_wt<1, 1>(a, co_t, ci_t, tiles_cc, st);
-  else if (d->mode == PTI_CONV_S2PAD) launch_wt<3, 2>(a, co_t, ci_t, tiles_cc, st);
-  else launch_wt<3, 1>(a, co_t, ci_t, tiles_cc, st);
+  if (v3) hipLaunchKernelGGL(wgrad_mfma3_kernel, dim3(tiles_cc * S), dim3(192), 0, st, a);
+  else if (d->ksize == 1) launch_wt<1, 1>(a, co_t, ci_t, tiles_cc, st);
+  else launch_wt<3, 2>(a, co_t, ci_t, tiles_cc, st);
   PTI_CHECK_LAUNCH("conv_wgrad_mfma");
-  const long long total = a.slab_stride;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total / 4 + 15) / 16)), dim3(256), 0, st, (const float*)workspace,
-                     a.slab_stride, S, dw, dbias, d->cout, d->cin, kk, accumulate);
+  *splits_out = S;
+  return PTI_OK;
+}
+
+extern "C" int pti_conv_wgrad_reduce(const void* workspace, int splits, float* dw, float* dbias, int accumulate,
+                                     const pti_conv_desc* d, pti_stream_t s) {
+  if (!workspace || !dw || !d || splits < 1) PTI_FAIL(PTI_EINVAL, "conv_wgrad_reduce: bad arguments");
+  const int kk = d->ksize * d->ksize;
+  const long long total = (long long)kk * d->cout * d->cin + d->cout;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total / 4 + 15) / 16)), dim3(256), 0, (hipStream_t)s,
+                     (const float*)workspace, total, splits, dw, dbias, d->cout, d->cin, kk, accumulate);
   PTI_CHECK_LAUNCH("conv_wgrad_reduce");
   return PTI_OK;
+}
+
+extern "C" int pti_conv_wgrad_mfma(const void* x, const void* dy, const float* in_stats, const float* gamma,
+                                   const float* beta, float* dw, float* dbias, void* workspace,
+                                   int64_t workspace_bytes, int accumulate, const pti_conv_desc* d, pti_stream_t s) {
+  if (!dw) PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma: null pointer");
+  int splits = 0;
+  if (int rc = pti_conv_wgrad_mfma_partials(x, dy, in_stats, gamma, beta, workspace, workspace_bytes, d, &splits, s)) return rc;
+  return pti_conv_wgrad_reduce(workspace, splits, dw, dbias, accumulate, d, s);
 }

@@ -130,7 +130,7 @@ def conv_mfma(x, w_packed, bias, y, *, cout, ksize=3, mode=PTI_CONV_S1, prologue
                 "pti_conv2d_mfma")
     if prof is not None:
         e1.record()
-        name = _conv_kernel_name(ksize, mode, cin, cout)
+        name = _conv_kernel_name(ksize, mode, cin, cout, act_out is not None)
         # algorithmic work; the zero-insert data gradient only has 1/4 useful taps per output pixel
         flops = 2.0 * n * ho * wo * cout * cin * ksize * ksize * (0.25 if mode == PTI_CONV_ZINS else 1.0)
         # algorithmic bytes: read the input once (bf16), write the output once (+ residual read)
@@ -139,13 +139,13 @@ def conv_mfma(x, w_packed, bias, y, *, cout, ksize=3, mode=PTI_CONV_S1, prologue
     return y
 
 
-def _conv_kernel_name(ksize, mode, cin, cout):
+def _conv_kernel_name(ksize, mode, cin, cout, save=False):
     """Template instantiation the C side picks (mirrors pick_cout_tile / pick_ck / pick_ck2), as rocprof names it."""
     ct = 128 if cout % 128 == 0 else (64 if cout % 64 == 0 else 32)
     ck = 128 if cin % 128 == 0 else (64 if cin % 64 == 0 else 32)
     if mode == PTI_CONV_S2PAD:
         return f"conv_mfma_kernel<3, 2, {min(ck, 64)}, {ct}>"
-    return f"conv_mfma2_kernel<{ksize}, {min(ck, ct)}, {ct}, {4 if ct == 128 else 2}>"
+    return f"conv_mfma2_kernel<{ksize}, {min(ck, ct)}, {ct}, {4 if ct == 128 else 2}, {str(save).lower()}>"
 
 
 # Set to a list to make conv_mfma record (kernel name, algorithmic flops, bytes, start, end events) per
@@ -236,10 +236,37 @@ def conv_wgrad_mfma(x, dy, dw, dbias, *, ksize=3, mode=PTI_CONV_S1, prologue=PTI
     ws = workspace if workspace is not None else wgrad_workspace(x.device)
     d = ConvDesc(n=n, h=h, w=w, cin=cin, ho=ho, wo=wo, cout=cout, ksize=ksize, mode=mode, prologue=prologue,
                  groups=groups, eps=eps)
-    L.check(L.lib().pti_conv_wgrad_mfma(_ptr(x), _ptr(dy), _ptr(in_stats), _ptr(gamma), _ptr(beta), _ptr(dw),
-                                        _ptr(dbias), _ptr(ws), ws.numel() * 4, int(accumulate), C.byref(d),
-                                        _stream()), "pti_conv_wgrad_mfma")
+    prof = KERNEL_PROFILE
+    if prof is None:
+        L.check(L.lib().pti_conv_wgrad_mfma(_ptr(x), _ptr(dy), _ptr(in_stats), _ptr(gamma), _ptr(beta), _ptr(dw),
+                                            _ptr(dbias), _ptr(ws), ws.numel() * 4, int(accumulate), C.byref(d),
+                                            _stream()), "pti_conv_wgrad_mfma")
+        return dw
+    # profiling: the same two launches through the two-call form, with events around the partial (MFMA) kernel only
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    splits = C.c_int(0)
+    e0.record()
+    L.check(L.lib().pti_conv_wgrad_mfma_partials(_ptr(x), _ptr(dy), _ptr(in_stats), _ptr(gamma), _ptr(beta), _ptr(ws),
+                                                 ws.numel() * 4, C.byref(d), C.byref(splits), _stream()),
+            "pti_conv_wgrad_mfma_partials")
+    e1.record()
+    L.check(L.lib().pti_conv_wgrad_reduce(_ptr(ws), splits.value, _ptr(dw), _ptr(dbias), int(accumulate), C.byref(d),
+                                          _stream()), "pti_conv_wgrad_reduce")
+    flops = 2.0 * n * ho * wo * cout * cin * ksize * ksize
+    # algorithmic bytes: x and dy read once (bf16); dw itself is negligible (the split-K slabs are not algorithmic)
+    prof.append((_wgrad_kernel_name(ksize, mode, cin, cout, n * ((ho + 7) // 8) * ((wo + 15) // 16)), flops,
+                 2.0 * (x.numel() + dy.numel()), e0, e1))
     return dw
+
+
+def _wgrad_kernel_name(ksize, mode, cin, cout, ntiles):
+    """Kernel symbol pti_conv_wgrad_mfma picks (mirrors its tile choice), as rocprof names it."""
+    if ksize == 3 and mode != PTI_CONV_S2PAD:
+        return "wgrad_mfma3_kernel"
+    co_t, ci_t = (64 if cout % 64 == 0 else 32), (64 if cin % 64 == 0 else 32)
+    if ntiles * (cout // co_t) * (cin // ci_t) < 16 * 512:
+        co_t = ci_t = 32
+    return f"wgrad_mfma_kernel<{ksize}, {2 if mode == PTI_CONV_S2PAD else 1}, {co_t}, {ci_t}>"
 
 
 def gn_bwd(x, da, dx, stats, gamma, beta, sums, dgamma, dbeta, *, groups, eps=1e-6, silu=True, dres=None):

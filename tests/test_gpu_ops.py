@@ -130,8 +130,8 @@ def test_conv_mfma(dev, n, cin, cout, h, w, ks, mode, pro, res, ostats):
     st = ops.gn_stats(xd, groups) if pro else None
     og = 16
     ost = torch.zeros(n, og, 2, device=dev) if ostats else None
-    # S1 + prologue launches also exercise the side output act_out = prologue(x) (pti_conv2d_mfma_saveact)
-    act = torch.full_like(xd, float("nan")) if (pro and mode == "s1") else None
+    # 3x3 S1 + prologue launches also exercise the side output act_out = prologue(x) (pti_conv2d_mfma_saveact)
+    act = torch.full_like(xd, float("nan")) if (pro and mode == "s1" and ks == 3) else None
     ops.conv_mfma(xd, wp, bias.to(dev), y, cout=cout, ksize=ks, mode=m, prologue=pro, in_stats=st,
                   gamma=gamma.to(dev) if pro else None, beta=beta.to(dev) if pro else None, groups=groups, eps=eps,
                   residual=_nhwc(rs).to(dev, torch.bfloat16) if res else None, out_stats=ost, out_groups=og, act_out=act)
