@@ -60,6 +60,12 @@ typedef struct pti_conv_desc {
   int32_t out_f32;        /* direct conv only: output is fp32 with explicit element strides  */
   int64_t in_stride[4];   /* n,h,w,c element strides when in_f32 (else NHWC dense)           */
   int64_t out_stride[4];  /* n,h,w,c element strides when out_f32                            */
+  /* 16-bit storage format of the NHWC activation operands: 0 = bf16, 1 = IEEE fp16.  The forward */
+  /* pass may keep its activations in fp16 (same bytes, 8x finer rounding); MFMA operands, saved  */
+  /* activated inputs, attention tensors and all gradients are bf16.  res_f16 also describes the  */
+  /* GroupNorm input `gx` of pti_conv2d_mfma_gnbwd.                                               */
+  int32_t in_f16, res_f16, out_f16;
+  int32_t reserved_;
 } pti_conv_desc;
 
 int pti_abi_version(void);
@@ -87,8 +93,8 @@ int pti_conv_pack_weights_batched(const void* table_dev, const int* blk_first_de
 
 /* ---- GroupNorm statistics (nn.GroupNorm's reduction) ---------------------------------- */
 /* stats[n][g] += {sum, sumsq} of x[n, :, channels of g]; stats must be zeroed by the caller. */
-int pti_gn_stats(const void* x_nhwc_bf16, float* stats, int n, int hw, int c, int groups,
-                 pti_stream_t s);
+int pti_gn_stats(const void* x_nhwc_16bit, float* stats, int n, int hw, int c, int groups,
+                 int x_f16, pti_stream_t s);
 
 /* ---- convolutions ---------------------------------------------------------------------- */
 /* Implicit-GEMM 3x3 / 1x1 convolution on bf16 MFMA (v_mfma_f32_32x32x16_bf16), fp32 accumulate:
@@ -121,7 +127,7 @@ int pti_conv2d_direct(const void* x, const float* w_tck, const float* bias, cons
 int pti_wgrad_direct(const void* wide, const void* narrow, float* dw, float* dbias_wide,
                      float* dbias_narrow, const float* in_stats, const float* gamma,
                      const float* beta, int n, int h, int w, int cw, int cn, int ksize, int sgn,
-                     int prologue, int groups, float eps, int narrow_f32,
+                     int prologue, int groups, float eps, int narrow_f32, int wide_f16,
                      const int64_t* narrow_stride, int64_t dw_stride_tap, int64_t dw_stride_cw,
                      int64_t dw_stride_k, void* workspace, int64_t workspace_bytes, pti_stream_t s);
 
@@ -149,7 +155,7 @@ int pti_conv_wgrad_reduce(const void* workspace, int splits, float* dw, float* d
  * [n][c][2] scratch; stats as produced by pti_gn_stats on x.  (autograd of nn.GroupNorm+F.silu) */
 int pti_gn_bwd(const void* x, const void* da, const void* dres, void* dx, const float* stats,
                const float* gamma, const float* beta, float* sums, float* dgamma, float* dbeta,
-               int n, int hw, int c, int groups, float eps, int silu, pti_stream_t s);
+               int n, int hw, int c, int groups, float eps, int silu, int x_f16, pti_stream_t s);
 /* Fused form used by the engine: the data-gradient conv computes dy = dA * act'(GN(gx)) in its epilogue and
  * accumulates gsums[n][c] = {sum dy, sum dy*xhat} (gx = the GroupNorm input, same shape as the conv output;
  * d->groups / d->eps describe that GroupNorm; d is a plain stride-1 / zero-insert launch, w_packed the
@@ -159,7 +165,8 @@ int pti_conv2d_mfma_gnbwd(const void* dy_in, const void* w_packed, const void* g
                           const pti_conv_desc* d, int silu, pti_stream_t s);
 int pti_gn_bwd_apply(const void* x, const void* dy, const void* dres, void* dx, const float* stats,
                      const float* gamma, const float* beta, const float* sums, float* dgamma,
-                     float* dbeta, int n, int hw, int c, int groups, float eps, pti_stream_t s);
+                     float* dbeta, int n, int hw, int c, int groups, float eps, int x_f16,
+                     pti_stream_t s);
 /* y[n,h,w,c] = sum of the 2x2 block of x[n,2h,2w,c]: backward of nn.Upsample(nearest, 2x).     */
 int pti_pool2x2_sum(const void* x, void* y, int n, int h, int w, int c, pti_stream_t s);
 

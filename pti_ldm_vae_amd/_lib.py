@@ -25,6 +25,7 @@ class ConvDesc(C.Structure):
         ("add_residual", C.c_int32), ("accum_stats", C.c_int32), ("out_groups", C.c_int32),
         ("eps", C.c_float), ("in_f32", C.c_int32), ("out_f32", C.c_int32),
         ("in_stride", C.c_int64 * 4), ("out_stride", C.c_int64 * 4),
+        ("in_f16", C.c_int32), ("res_f16", C.c_int32), ("out_f16", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 
@@ -43,19 +44,19 @@ SIGNATURES = {
     "pti_conv_pack_entry_bytes": (_I, []),
     "pti_conv_pack_table_fill": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, C.POINTER(_I64)]),
     "pti_conv_pack_weights_batched": (_I, [_P, _P, _I, _I, _P]),
-    "pti_gn_stats": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "pti_gn_stats": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "pti_conv2d_mfma": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(ConvDesc), _P]),
     "pti_conv2d_mfma_saveact": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(ConvDesc), _P]),
     "pti_conv2d_direct": (_I, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(ConvDesc), _P]),
-    "pti_wgrad_direct": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I,
+    "pti_wgrad_direct": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I,
                               C.POINTER(_I64), _I64, _I64, _I64, _P, _I64, _P]),
     "pti_conv_wgrad_workspace_bytes": (_I64, [_I, _I, _I, _I]),
     "pti_conv_wgrad_mfma": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I, C.POINTER(ConvDesc), _P]),
     "pti_conv_wgrad_mfma_partials": (_I, [_P, _P, _P, _P, _P, _P, _I64, C.POINTER(ConvDesc), C.POINTER(_I), _P]),
     "pti_conv_wgrad_reduce": (_I, [_P, _I, _P, _P, _I, C.POINTER(ConvDesc), _P]),
-    "pti_gn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
+    "pti_gn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _P]),
     "pti_conv2d_mfma_gnbwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(ConvDesc), _I, _P]),
-    "pti_gn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "pti_gn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
     "pti_pool2x2_sum": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "pti_attention_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "pti_attention_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

@@ -23,6 +23,7 @@ struct DArgs {
   int prologue, groups;
   float eps, inv_cnt;
   int in_f32, out_f32, w_lds;
+  int wide_f16;   // the wide NHWC 16-bit tensor (output of few-cin, input of few-cout) is fp16, else bf16
   long long is[4], os[4];  // n,h,w,c element strides of the narrow tensor(s)
 };
 
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void direct_fewcin_kernel(DArgs a) {
   }
   bf16* yo = (bf16*)a.y + (size_t)pix * a.Cout + cb;
 #pragma unroll
-  for (int c = 0; c < 32; c += 8) *(u32x4*)(yo + c) = pack8(acc + c);
+  for (int c = 0; c < 32; c += 8) *(u32x4*)(yo + c) = pack8f(acc + c, a.wide_f16);
 }
 
 // ---- many input channels (NHWC bf16 dense, cin % 8 == 0, cin/8 | 64) -> few output channels ----
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256) void direct_fewcout_kernel(DArgs a) {
     for (int t = 0; t < 9; ++t) {
       if (!ok[t]) continue;
       float f[8];
-      unpack8(raw[t], f);
+      unpack8f(raw[t], f, a.wide_f16);
       if (a.prologue) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -189,6 +190,7 @@ struct WGArgs {
   int N, H, W, CW, KS, sgn;
   int prologue, groups; float eps, inv_cnt;
   int narrow_f32; long long ns[4];
+  int wide_f16;
   long long dw_stride_tap, dw_stride_cw, dw_stride_k;
 };
 
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(WGArgs a) {
       }
     }
     float f[8];
-    unpack8(*(const u32x4*)(a.wide + (size_t)pix * a.CW + lc * 8), f);
+    unpack8f(*(const u32x4*)(a.wide + (size_t)pix * a.CW + lc * 8), f, a.wide_f16);
     if (a.dbias_wide && k == 0) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) bsum[j] += f[j];
@@ -342,7 +344,7 @@ static int fill_common(DArgs& a, const void* x, const float* w, const float* bia
   a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout; a.KS = d->ksize;
   a.prologue = d->prologue; a.groups = d->groups; a.eps = d->eps;
   a.inv_cnt = d->prologue ? 1.0f / ((float)(d->cin / d->groups) * (float)d->h * (float)d->w) : 0.f;
-  a.in_f32 = d->in_f32; a.out_f32 = d->out_f32; a.w_lds = 0;
+  a.in_f32 = d->in_f32; a.out_f32 = d->out_f32; a.w_lds = 0; a.wide_f16 = 0;
   for (int i = 0; i < 4; ++i) { a.is[i] = d->in_stride[i]; a.os[i] = d->out_stride[i]; }
   return 0;
 }
@@ -358,11 +360,13 @@ extern "C" int pti_conv2d_direct(const void* x, const float* w, const float* bia
   const long long npix = (long long)d->n * d->h * d->w;
   if (d->cout % 32 == 0 && d->cin <= 16) {  // few cin -> many cout
     if (d->prologue) PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_direct: prologue on the narrow input");
-    if (d->out_f32) PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_direct: wide output must be bf16 NHWC");
+    if (d->out_f32) PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_direct: wide output must be 16-bit NHWC");
+    a.wide_f16 = d->out_f16;
     dim3 grid((unsigned)((npix + 255) / 256), d->cout / 32);
     hipLaunchKernelGGL(direct_fewcin_kernel, grid, dim3(256), 0, (hipStream_t)s, a);
   } else if (d->cout <= 16 && d->cin % 8 == 0 && d->cin >= 8 && d->cin <= 512 && !(d->cin & (d->cin - 1))) {
-    if (d->in_f32) PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_direct: wide input must be bf16 NHWC");
+    if (d->in_f32) PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_direct: wide input must be 16-bit NHWC");
+    a.wide_f16 = d->in_f16;
     if (d->prologue && (!in_stats || !gamma || !beta || d->groups <= 0 || d->cin % d->groups))
       PTI_FAIL(PTI_EINVAL, "conv2d_direct: prologue needs stats/gamma/beta");
     const int ppb = 256 / (d->cin / 8);
@@ -386,7 +390,7 @@ extern "C" int pti_conv2d_direct(const void* x, const float* w, const float* bia
 extern "C" int pti_wgrad_direct(const void* wide, const void* narrow, float* dw, float* dbias_wide,
                                 float* dbias_narrow, const float* in_stats, const float* gamma, const float* beta,
                                 int n, int h, int w, int cw, int cn, int ksize, int sgn, int prologue, int groups,
-                                float eps, int narrow_f32, const int64_t* narrow_stride, int64_t dw_stride_tap,
+                                float eps, int narrow_f32, int wide_f16, const int64_t* narrow_stride, int64_t dw_stride_tap,
                                 int64_t dw_stride_cw, int64_t dw_stride_k, void* workspace, int64_t workspace_bytes,
                                 pti_stream_t s) {
   if (!wide || !narrow || !dw || !narrow_stride || !workspace) PTI_FAIL(PTI_EINVAL, "wgrad_direct: null pointer");
@@ -399,7 +403,7 @@ extern "C" int pti_wgrad_direct(const void* wide, const void* narrow, float* dw,
   a.N = n; a.H = h; a.W = w; a.CW = cw; a.KS = ksize; a.sgn = sgn;
   a.prologue = prologue; a.groups = groups; a.eps = eps;
   a.inv_cnt = prologue ? 1.0f / ((float)(cw / groups) * (float)h * (float)w) : 0.f;
-  a.narrow_f32 = narrow_f32;
+  a.narrow_f32 = narrow_f32; a.wide_f16 = wide_f16;
   for (int i = 0; i < 4; ++i) a.ns[i] = narrow_stride[i];
   a.dw_stride_tap = dw_stride_tap; a.dw_stride_cw = dw_stride_cw; a.dw_stride_k = dw_stride_k;
   const long long npix = (long long)n * h * w;

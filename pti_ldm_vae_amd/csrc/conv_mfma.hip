@@ -81,6 +81,8 @@ struct ConvArgs {
   // optional side output (v2 kernel, PTI_CONV_S1 with a prologue): the activated input act(GN(x)) as bf16 NHWC,
   // written by the cout-tile-0 workgroups from their staging registers, for the weight-gradient pass to reuse
   bf16* act_out;
+  // 16-bit storage format of x / residual (or the GN input of the fused backward) / y: 0 = bf16, 1 = fp16
+  int in_f16, res_f16, out_f16;
 };
 
 template <int KS, int S, int CK, int COUT_TILE>
@@ -203,13 +205,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
         u32x4 r = raw[it];
         if (a.prologue != PTI_PRO_NONE && ok[it]) {
           float f[8];
-          unpack8(r, f);
+          unpack8f(r, f, a.in_f16);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             float v = f[j] * sc[j] + sh[j];
             if (a.prologue == PTI_PRO_GN_SILU) v = silu_f(v);
             f[j] = v;
           }
+          r = pack8(f);
+        } else if (a.in_f16) {   // no prologue: the MFMA operand is bf16, convert the fp16 piece
+          float f[8];
+          unpack8f(r, f, true);
           r = pack8(f);
         }
         const int key = (hx >> C::KEY_SHIFT) & (C::NC - 1);
@@ -280,18 +286,19 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
         if (inb) {
           if (a.res) {
             const u32x2 rr = *(const u32x2*)(a.res + pix + co);
-            v0 += __uint_as_float(rr[0] << 16);
-            v1 += __uint_as_float(rr[0] & 0xffff0000u);
-            v2 += __uint_as_float(rr[1] << 16);
-            v3 += __uint_as_float(rr[1] & 0xffff0000u);
+            float e0, e1, e2, e3;
+            unpack2f(rr[0], a.res_f16, e0, e1);
+            unpack2f(rr[1], a.res_f16, e2, e3);
+            v0 += e0; v1 += e1; v2 += e2; v3 += e3;
           }
-          packed = pack4(v0, v1, v2, v3);
+          packed = pack4f(v0, v1, v2, v3, a.out_f16);
           *(u32x2*)(a.y + pix + co) = packed;
         }
         if (do_stats) {
-          // statistics of the values as stored (bf16-rounded), like a later read pass would see
-          float r0 = __uint_as_float(packed[0] << 16), r1 = __uint_as_float(packed[0] & 0xffff0000u);
-          float r2 = __uint_as_float(packed[1] << 16), r3 = __uint_as_float(packed[1] & 0xffff0000u);
+          // statistics of the values as stored (rounded to 16 bits), like a later read pass would see
+          float r0, r1, r2, r3;
+          unpack2f(packed[0], a.out_f16, r0, r1);
+          unpack2f(packed[1], a.out_f16, r2, r3);
           if (!inb) r0 = r1 = r2 = r3 = 0.f;
           if (ocpg >= 4) {
             float s1 = (r0 + r1) + (r2 + r3), s2 = (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
@@ -520,13 +527,17 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
         u32x4 r = raw[it];
         if (a.prologue != PTI_PRO_NONE && ok[it]) {
           float f[8];
-          unpack8(r, f);
+          unpack8f(r, f, a.in_f16);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             float v = f[j] * sc[j] + sh[j];
             if (a.prologue == PTI_PRO_GN_SILU) v = silu_f(v);
             f[j] = v;
           }
+          r = pack8(f);
+        } else if (a.in_f16) {   // no prologue: the MFMA operand is bf16, convert the fp16 piece
+          float f[8];
+          unpack8f(r, f, true);
           r = pack8(f);
         }
         const int key = (hx >> C::KEY_SHIFT) & (C::NC - 1);
@@ -656,8 +667,9 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
         const bool inb = (oy0 + (p >> 4) < a.Ho) && (ox0 + (p & 15) < a.Wo);
         unsigned char* ep = etile + p * C::EPITCH + col * 2;
         const u32x2 rr = *(const u32x2*)ep;
-        float xv[4] = {__uint_as_float(rr[0] << 16), __uint_as_float(rr[0] & 0xffff0000u),
-                       __uint_as_float(rr[1] << 16), __uint_as_float(rr[1] & 0xffff0000u)};
+        float xv[4];
+        unpack2f(rr[0], a.res_f16, xv[0], xv[1]);
+        unpack2f(rr[1], a.res_f16, xv[2], xv[3]);
         float dv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -703,16 +715,17 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
       unsigned char* ep = etile + p * C::EPITCH + col * 2;
       if (a.res) {
         const u32x2 rr = *(const u32x2*)ep;
-        v0 += __uint_as_float(rr[0] << 16);
-        v1 += __uint_as_float(rr[0] & 0xffff0000u);
-        v2 += __uint_as_float(rr[1] << 16);
-        v3 += __uint_as_float(rr[1] & 0xffff0000u);
+        float e0, e1, e2, e3;
+        unpack2f(rr[0], a.res_f16, e0, e1);
+        unpack2f(rr[1], a.res_f16, e2, e3);
+        v0 += e0; v1 += e1; v2 += e2; v3 += e3;
       }
-      const u32x2 packed = pack4(v0, v1, v2, v3);
+      const u32x2 packed = pack4f(v0, v1, v2, v3, a.out_f16);
       *(u32x2*)ep = packed;
       if (do_stats && inb) {
-        const float r0 = __uint_as_float(packed[0] << 16), r1 = __uint_as_float(packed[0] & 0xffff0000u);
-        const float r2 = __uint_as_float(packed[1] << 16), r3 = __uint_as_float(packed[1] & 0xffff0000u);
+        float r0, r1, r2, r3;
+        unpack2f(packed[0], a.out_f16, r0, r1);
+        unpack2f(packed[1], a.out_f16, r2, r3);
         if (ocpg >= 4) {
           st1[q] += (r0 + r1) + (r2 + r3);
           st2[q] += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
@@ -995,6 +1008,7 @@ static int conv2d_mfma_impl(const void* x, const void* w_packed, const float* bi
   a.gn_mode = 0; a.g_groups = 0; a.g_inv_cnt = 0.f; a.g_eps = 0.f;
   a.g_stats = a.g_gamma = a.g_beta = nullptr; a.g_sums = nullptr;
   a.act_out = (bf16*)act_out;
+  a.in_f16 = d->in_f16; a.res_f16 = d->res_f16; a.out_f16 = d->out_f16;
   a.eps = d->eps;
   a.inv_cnt = d->prologue != PTI_PRO_NONE ? 1.0f / ((float)(d->cin / d->groups) * (float)d->h * (float)d->w) : 0.f;
   if (gf) {

@@ -10,7 +10,7 @@ namespace {
 
 // stats[n][g] += {sum, sumsq}.  grid = (blocks_per_sample, N), block = 256.
 __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16* __restrict__ x, float* __restrict__ stats,
-                                                       int HW, int C, int G, int pix_per_block) {
+                                                       int HW, int C, int G, int pix_per_block, int x_f16) {
   extern __shared__ float sm[];  // [G][2]
   const int n = blockIdx.y;
   const int tid = threadIdx.x;
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16* __restrict__ 
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       float f[8];
-      unpack8(r[u], f);
+      unpack8f(r[u], f, x_f16);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         s[j] += f[j];
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16* __restrict__ 
   for (; p < p1; p += ppi) {
     const u32x4 r = *(const u32x4*)(base + (size_t)p * C);
     float f[8];
-    unpack8(r, f);
+    unpack8f(r, f, x_f16);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       s[j] += f[j];
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16* __restrict__ 
 
 }  // namespace
 
-extern "C" int pti_gn_stats(const void* x, float* stats, int n, int hw, int c, int groups, pti_stream_t s) {
+extern "C" int pti_gn_stats(const void* x, float* stats, int n, int hw, int c, int groups, int x_f16, pti_stream_t s) {
   if (!x || !stats || n <= 0 || hw <= 0) PTI_FAIL(PTI_EINVAL, "gn_stats: bad pointer/dims");
   if (c < 8 || c > 2048 || (c & (c - 1)) || groups <= 0 || c % groups)
     PTI_FAIL(PTI_EUNSUPPORTED, "gn_stats: c=%d must be a power of two in [8,2048] and divisible by groups=%d", c, groups);
@@ -98,7 +98,7 @@ extern "C" int pti_gn_stats(const void* x, float* stats, int n, int hw, int c, i
   ppb = cdiv(ppb, 4 * ppi) * 4 * ppi;
   bps = cdiv(hw, ppb);
   hipLaunchKernelGGL(gn_stats_kernel, dim3(bps, n), dim3(256), 2 * groups * sizeof(float), (hipStream_t)s,
-                     (const bf16*)x, stats, hw, c, groups, ppb);
+                     (const bf16*)x, stats, hw, c, groups, ppb, x_f16);
   PTI_CHECK_LAUNCH("gn_stats");
   return PTI_OK;
 }
@@ -119,6 +119,7 @@ struct GnbArgs {
   float* dgamma; float* dbeta;
   int HW, C, G, silu, ppb;
   float eps, inv_cnt;
+  int x_f16;   // x (a forward activation) is stored fp16; da / dres / dx are gradients: always bf16
 };
 
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnbArgs a) {
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnbArgs a) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       float fx[8], fd[8];
-      unpack8(rx[u], fx);
+      unpack8f(rx[u], fx, a.x_f16);
       unpack8(rd[u], fd);   // da == 0 for the padded lanes => they add nothing
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnbArgs a) {
     for (int u = 0; u < U; ++u) {
       const int p = pb + u * ppi;
       float fx[8], fd[8], fr[8], o[8];
-      unpack8(rx[u], fx);
+      unpack8f(rx[u], fx, a.x_f16);
       unpack8(rd[u], fd);
       unpack8(rr[u], fr);
 #pragma unroll
@@ -308,13 +309,13 @@ __global__ __launch_bounds__(256) void pool2x2_sum_kernel(const bf16* __restrict
 
 extern "C" int pti_gn_bwd(const void* x, const void* da, const void* dres, void* dx, const float* stats,
                           const float* gamma, const float* beta, float* sums, float* dgamma, float* dbeta, int n,
-                          int hw, int c, int groups, float eps, int silu, pti_stream_t s) {
+                          int hw, int c, int groups, float eps, int silu, int x_f16, pti_stream_t s) {
   if (!x || !da || !dx || !stats || !gamma || !beta || !sums) PTI_FAIL(PTI_EINVAL, "gn_bwd: null pointer");
   if (c < 8 || c > 2048 || (c & (c - 1)) || groups <= 0 || c % groups) PTI_FAIL(PTI_EUNSUPPORTED, "gn_bwd: c=%d groups=%d", c, groups);
   GnbArgs a;
   a.x = (const bf16*)x; a.da = (const bf16*)da; a.dres = (const bf16*)dres; a.dx = (bf16*)dx;
   a.stats = stats; a.gamma = gamma; a.beta = beta; a.sums = sums; a.dgamma = dgamma; a.dbeta = dbeta;
-  a.HW = hw; a.C = c; a.G = groups; a.silu = silu; a.eps = eps;
+  a.HW = hw; a.C = c; a.G = groups; a.silu = silu; a.eps = eps; a.x_f16 = x_f16;
   a.inv_cnt = 1.0f / ((float)(c / groups) * (float)hw);
   const int ppi = 256 / (c / 8);
   int bps = cdiv(2048, n);
@@ -334,13 +335,13 @@ extern "C" int pti_gn_bwd(const void* x, const void* da, const void* dres, void*
 // (both produced by pti_conv2d_mfma_gnbwd in the data-gradient conv's epilogue)
 extern "C" int pti_gn_bwd_apply(const void* x, const void* dy, const void* dres, void* dx, const float* stats,
                                 const float* gamma, const float* beta, const float* sums, float* dgamma, float* dbeta,
-                                int n, int hw, int c, int groups, float eps, pti_stream_t s) {
+                                int n, int hw, int c, int groups, float eps, int x_f16, pti_stream_t s) {
   if (!x || !dy || !dx || !stats || !gamma || !beta || !sums) PTI_FAIL(PTI_EINVAL, "gn_bwd_apply: null pointer");
   if (c < 8 || c > 2048 || (c & (c - 1)) || groups <= 0 || c % groups) PTI_FAIL(PTI_EUNSUPPORTED, "gn_bwd_apply: c=%d groups=%d", c, groups);
   GnbArgs a;
   a.x = (const bf16*)x; a.da = (const bf16*)dy; a.dres = (const bf16*)dres; a.dx = (bf16*)dx;
   a.stats = stats; a.gamma = gamma; a.beta = beta; a.sums = const_cast<float*>(sums); a.dgamma = dgamma; a.dbeta = dbeta;
-  a.HW = hw; a.C = c; a.G = groups; a.silu = 0; a.eps = eps;
+  a.HW = hw; a.C = c; a.G = groups; a.silu = 0; a.eps = eps; a.x_f16 = x_f16;
   a.inv_cnt = 1.0f / ((float)(c / groups) * (float)hw);
   const int ppi = 256 / (c / 8);
   int bps = cdiv(2048, n);

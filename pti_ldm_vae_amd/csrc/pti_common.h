@@ -62,6 +62,50 @@ __device__ __forceinline__ u32x2 pack4(float a, float b, float c, float d) {
   r[1] = __builtin_bit_cast(uint32_t, p1);
   return r;
 }
+// ---- 16-bit activation formats -----------------------------------------------------------------
+// Activations written by the FORWARD pass may be stored as IEEE fp16 (11-bit significand) instead of bf16: same
+// bytes, 8x smaller rounding step, and GroupNorm keeps their range far inside fp16's.  MFMA operands, saved
+// activated inputs, attention tensors and every gradient stay bf16.  `f16` flags are wave-uniform.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void unpack2f(uint32_t w, bool f16, float& a, float& b) {
+  if (f16) {
+    const f16x2 h = __builtin_bit_cast(f16x2, w);
+    a = (float)h[0];
+    b = (float)h[1];
+  } else {
+    a = __uint_as_float(w << 16);
+    b = __uint_as_float(w & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ uint32_t pack2f(float a, float b, bool f16) {
+  if (f16) {
+    f16x2 h;
+    h[0] = (_Float16)a;
+    h[1] = (_Float16)b;
+    return __builtin_bit_cast(uint32_t, h);
+  }
+  bf16x2 p;
+  p[0] = (bf16)a;
+  p[1] = (bf16)b;
+  return __builtin_bit_cast(uint32_t, p);
+}
+__device__ __forceinline__ void unpack8f(const u32x4& r, float* f, bool f16) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) unpack2f(r[i], f16, f[2 * i], f[2 * i + 1]);
+}
+__device__ __forceinline__ u32x4 pack8f(const float* f, bool f16) {
+  u32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = pack2f(f[2 * i], f[2 * i + 1], f16);
+  return r;
+}
+__device__ __forceinline__ u32x2 pack4f(float a, float b, float c, float d, bool f16) {
+  u32x2 r;
+  r[0] = pack2f(a, b, f16);
+  r[1] = pack2f(c, d, f16);
+  return r;
+}
+
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
 // d silu(v)/dv = s*(1 + v*(1-s)), s = sigmoid(v)
 __device__ __forceinline__ float dsilu_f(float v) {

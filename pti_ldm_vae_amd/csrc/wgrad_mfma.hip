@@ -30,6 +30,7 @@ struct WgArgs {
   int tiles_x, tiles_y, ntiles, S;
   int ci_tiles;
   long long slab_stride;
+  int x_f16;   // x is a forward activation stored fp16 (converted to the bf16 MFMA operand in the loader)
 };
 
 template <int KS, int S_, int CO_T, int CI_T>
@@ -143,13 +144,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgArgs a) {
         u32x4 r = araw[it];
         if (a.prologue != PTI_PRO_NONE && aok[it]) {
           float f[8];
-          unpack8(r, f);
+          unpack8f(r, f, a.x_f16);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             float v = f[j] * sc[j] + sh[j];
             if (a.prologue == PTI_PRO_GN_SILU) v = silu_f(v);
             f[j] = v;
           }
+          r = pack8(f);
+        } else if (a.x_f16) {
+          float f[8];
+          unpack8f(r, f, true);
           r = pack8(f);
         }
         *(u32x4*)(lA + p * C::PA + alc * 16) = r;
@@ -368,13 +373,17 @@ __global__ __launch_bounds__(192) void wgrad_mfma3_kernel(WgArgs a) {
         u32x4 r = araw[it];
         if (a.prologue != PTI_PRO_NONE && ((aokm >> it) & 1u)) {
           float f[8];
-          unpack8(r, f);
+          unpack8f(r, f, a.x_f16);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             float v = f[j] * sc[j] + sh[j];
             if (a.prologue == PTI_PRO_GN_SILU) v = silu_f(v);
             f[j] = v;
           }
+          r = pack8(f);
+        } else if (a.x_f16) {
+          float f[8];
+          unpack8f(r, f, true);
           r = pack8(f);
         }
         *(u32x4*)(lA + p * C::PP + lc * 16) = r;
@@ -527,7 +536,7 @@ extern "C" int pti_conv_wgrad_mfma_partials(const void* x, const void* dy, const
   a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.in_stats = in_stats; a.gamma = gamma; a.beta = beta;
   a.slab = (float*)workspace;
   a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Ho = d->ho; a.Wo = d->wo; a.Cout = d->cout;
-  a.mode = d->mode; a.prologue = d->prologue; a.groups = d->groups; a.eps = d->eps;
+  a.mode = d->mode; a.prologue = d->prologue; a.groups = d->groups; a.eps = d->eps; a.x_f16 = d->in_f16;
   a.inv_cnt = d->prologue != PTI_PRO_NONE ? 1.0f / ((float)(d->cin / d->groups) * (float)d->h * (float)d->w) : 0.f;
   a.tiles_x = cdiv(d->wo, TW); a.tiles_y = cdiv(d->ho, TH); a.ntiles = d->n * a.tiles_x * a.tiles_y;
   // Tile / split choice.  3x3 stride-1 gathers: the tap-split 32x32 kernel (v3, measured faster on every such

@@ -81,10 +81,11 @@ class _MfmaConv:
         self.wpt = ops.pack_conv_weight(w, self.ksize, dmode, flip=True, out=self.wpt)
 
     # y = conv(prologue(x)) + b [+ residual]; optional fused stats of y
-    def fwd(self, x, *, pro=PTI_PRO_NONE, norm=None, residual=None, want_stats=False, eng=None, act_out=None):
+    def fwd(self, x, *, pro=PTI_PRO_NONE, norm=None, residual=None, want_stats=False, eng=None, act_out=None,
+            out_dtype=None):
         n, h, w, _ = x.t.shape
         ho, wo = ops.conv_out_hw(h, w, self.mode)
-        y = _empty((n, ho, wo, self.cout), x.t)
+        y = _empty((n, ho, wo, self.cout), x.t, out_dtype or eng.act_dtype)
         st = eng.new_stats(n) if want_stats else None
         g, b = (norm.weight.data, norm.bias.data) if norm is not None else (None, None)
         ops.conv_mfma(x.t, self.wp, self.bias(), y, cout=self.cout, ksize=self.ksize, mode=self.mode, prologue=pro,
@@ -226,7 +227,7 @@ class _Attention:
 
     def fwd(self, x, eng, want_stats, save):
         n, h, w, c = x.t.shape
-        qkv = self.qkv.fwd(x, pro=PTI_PRO_GN, norm=self.norm, eng=eng).t
+        qkv = self.qkv.fwd(x, pro=PTI_PRO_GN, norm=self.norm, eng=eng, out_dtype=BF16).t   # MFMA operand of attention
         o = _empty((n, h * w, c), x.t)
         lse = _empty((n, h * w), x.t, F32)
         ops.attention_fwd(qkv.view(n, h * w, 3 * c), o, lse)
@@ -297,6 +298,10 @@ class Engine:
         self._zpool, self._zoff, self._zpool_size = None, 0, 1 << 16
         self._packer = None
         self.save_act_min_hw = int(os.environ.get("PTI_SAVE_ACT_MIN_HW", "0"))
+        # storage format of the forward activations (residual stream, conv outputs): fp16 = same bytes as bf16 with
+        # an 8x finer rounding step (GroupNorm keeps the range far inside fp16's); MFMA operands, saved activated
+        # inputs, attention tensors and every gradient are bf16 either way.  PTI_FWD_ACT_DTYPE=bf16 restores bf16.
+        self.act_dtype = {"fp16": torch.float16, "bf16": BF16}[os.environ.get("PTI_FWD_ACT_DTYPE", "fp16")]
         ops.L.lib()  # fail loudly now if the HIP extension is missing
         for c in net.channels:
             if c % 32:
@@ -437,7 +442,7 @@ class Engine:
             raise ValueError(f"encode: H,W must be multiples of {down}, got {h}x{w}")
         self.begin_pass(n)
         c0 = self.net.channels[0]
-        t0 = _empty((n, h, w, c0), x)
+        t0 = _empty((n, h, w, c0), x, self.act_dtype)
         ops.conv_direct(x, self.enc_in.w_tck, self.enc_in.b.data, t0, n=n, h=h, w=w, cin=cin, cout=c0, x_layout="nchw")
         a0 = _Act(t0, ops.gn_stats(t0, self.G, self.new_stats(n)))
         saved = [] if save else None
@@ -512,7 +517,7 @@ class Engine:
         zq = _empty((n, hl * wl, L), z, F32)
         ops.post_quant(z, wp, bp, zq)
         di = self.dec_in
-        t0 = _empty((n, hl, wl, di.cout), z)
+        t0 = _empty((n, hl, wl, di.cout), z, self.act_dtype)
         ops.conv_direct(zq.view(n, hl, wl, L), di.w_tck, di.b.data, t0, n=n, h=hl, w=wl, cin=L, cout=di.cout)
         a0 = _Act(t0, ops.gn_stats(t0, self.G, self.new_stats(n)))
         saved = [] if save else None

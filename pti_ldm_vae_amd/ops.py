@@ -15,7 +15,9 @@ from ._lib import (PTI_CONV_S1, PTI_CONV_S2PAD, PTI_CONV_UP2, PTI_CONV_ZINS, PTI
                    PTI_PRO_NONE, ConvDesc)
 
 BF16 = torch.bfloat16
+F16 = torch.float16
 F32 = torch.float32
+ACT16 = (BF16, F16)   # storage formats of a forward activation (flag derived from the tensor's dtype)
 
 
 def _stream() -> int:
@@ -29,7 +31,7 @@ def _ptr(t):
 def _chk(t, dtype, name, dims=None):
     if not t.is_cuda:
         raise ValueError(f"{name}: expected a CUDA(HIP) tensor")
-    if t.dtype != dtype:
+    if (t.dtype not in dtype) if isinstance(dtype, tuple) else (t.dtype != dtype):
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
     if not t.is_contiguous():
         raise ValueError(f"{name}: must be contiguous")
@@ -68,8 +70,8 @@ def pack_conv_weight(ws, ksize, mode=PTI_CONV_S1, flip=False, out=None):
 
 
 def gn_stats(x, groups, stats=None):
-    """x: [N,H,W,C] bf16 -> stats [N,G,2] fp32 {sum, sumsq} (accumulated into ``stats`` if given)."""
-    _chk(x, BF16, "x", 4)
+    """x: [N,H,W,C] bf16|fp16 -> stats [N,G,2] fp32 {sum, sumsq} (accumulated into ``stats`` if given)."""
+    _chk(x, ACT16, "x", 4)
     n, h, w, c = x.shape
     if stats is None:
         stats = torch.zeros(n, groups, 2, dtype=F32, device=x.device)
@@ -77,15 +79,16 @@ def gn_stats(x, groups, stats=None):
         _chk(stats, F32, "stats")
         if stats.numel() != n * groups * 2:
             raise ValueError("gn_stats: stats size")
-    L.check(L.lib().pti_gn_stats(_ptr(x), _ptr(stats), n, h * w, c, groups, _stream()), "pti_gn_stats")
+    L.check(L.lib().pti_gn_stats(_ptr(x), _ptr(stats), n, h * w, c, groups, int(x.dtype == F16), _stream()),
+            "pti_gn_stats")
     return stats
 
 
 def conv_mfma(x, w_packed, bias, y, *, cout, ksize=3, mode=PTI_CONV_S1, prologue=PTI_PRO_NONE, in_stats=None,
               gamma=None, beta=None, groups=0, eps=1e-6, residual=None, out_stats=None, out_groups=0, act_out=None):
     """``act_out`` (optional, bf16, x's shape): also write prologue(x) for the weight-gradient pass to reuse."""
-    _chk(x, BF16, "x", 4)
-    _chk(y, BF16, "y", 4)
+    _chk(x, ACT16, "x", 4)
+    _chk(y, ACT16, "y", 4)
     n, h, w, cin = x.shape
     if act_out is not None:
         _chk(act_out, BF16, "act_out", 4)
@@ -106,7 +109,7 @@ def conv_mfma(x, w_packed, bias, y, *, cout, ksize=3, mode=PTI_CONV_S1, prologue
             if t.numel() != cnt:
                 raise ValueError(f"conv_mfma: {nm} size")
     if residual is not None:
-        _chk(residual, BF16, "residual", 4)
+        _chk(residual, ACT16, "residual", 4)
         if residual.shape != y.shape:
             raise ValueError("conv_mfma: residual shape")
     if out_stats is not None:
@@ -115,7 +118,8 @@ def conv_mfma(x, w_packed, bias, y, *, cout, ksize=3, mode=PTI_CONV_S1, prologue
             raise ValueError("conv_mfma: out_stats size")
     d = ConvDesc(n=n, h=h, w=w, cin=cin, ho=ho, wo=wo, cout=cout, ksize=ksize, mode=mode, prologue=prologue,
                  groups=groups, add_residual=int(residual is not None), accum_stats=int(out_stats is not None),
-                 out_groups=out_groups, eps=eps)
+                 out_groups=out_groups, eps=eps, in_f16=int(x.dtype == F16),
+                 res_f16=int(residual is not None and residual.dtype == F16), out_f16=int(y.dtype == F16))
     prof = KERNEL_PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -169,15 +173,16 @@ def conv_direct(x, w_tck, bias, y, *, n, h, w, cin, cout, ksize=3, x_layout="nhw
     if x.numel() != n * h * w * cin or y.numel() != n * h * w * cout:
         raise ValueError("conv_direct: tensor sizes do not match n,h,w,cin,cout")
     d = ConvDesc(n=n, h=h, w=w, cin=cin, ho=h, wo=w, cout=cout, ksize=ksize, mode=PTI_CONV_S1, prologue=prologue,
-                 groups=groups, eps=eps, in_f32=int(x.dtype == F32), out_f32=int(y.dtype == F32))
+                 groups=groups, eps=eps, in_f32=int(x.dtype == F32), out_f32=int(y.dtype == F32),
+                 in_f16=int(x.dtype == F16), out_f16=int(y.dtype == F16))
     d.in_stride = (C.c_int64 * 4)(*_strides4(x, x_layout))
     d.out_stride = (C.c_int64 * 4)(*_strides4(y, y_layout))
     if cout % 32 == 0 and cin <= 16:
-        if y.dtype != BF16 or not y.is_contiguous() or y_layout != "nhwc":
-            raise ValueError("conv_direct: wide output must be dense NHWC bf16")
+        if y.dtype not in ACT16 or not y.is_contiguous() or y_layout != "nhwc":
+            raise ValueError("conv_direct: wide output must be dense NHWC bf16/fp16")
     else:
-        if x.dtype != BF16 or not x.is_contiguous() or x_layout != "nhwc":
-            raise ValueError("conv_direct: wide input must be dense NHWC bf16")
+        if x.dtype not in ACT16 or not x.is_contiguous() or x_layout != "nhwc":
+            raise ValueError("conv_direct: wide input must be dense NHWC bf16/fp16")
     L.check(L.lib().pti_conv2d_direct(_ptr(x), _ptr(w_tck), _ptr(bias), _ptr(in_stats), _ptr(gamma), _ptr(beta),
                                       _ptr(y), C.byref(d), _stream()), "pti_conv2d_direct")
     return y
@@ -188,13 +193,14 @@ def wgrad_direct(wide, narrow, dw, *, n, h, w, cw, cn, ksize, sgn, narrow_layout
                  workspace=None):
     """dw[tap,cw,k] += sum_p narrow[p,k] * T(wide)[p + sgn*tap, cw]; dw_strides = (tap, cw, k) element
     strides into the fp32 OIHW gradient ``dw`` (must be zero-initialised or hold a running sum)."""
-    _chk(wide, BF16, "wide", 4)
+    _chk(wide, ACT16, "wide", 4)
     _chk(dw, F32, "dw")
     ns = (C.c_int64 * 4)(*_strides4(narrow, narrow_layout))
     ws = workspace if workspace is not None else wgrad_workspace(wide.device)
     L.check(L.lib().pti_wgrad_direct(_ptr(wide), _ptr(narrow), _ptr(dw), _ptr(dbias_wide), _ptr(dbias_narrow),
                                      _ptr(in_stats), _ptr(gamma), _ptr(beta), n, h, w, cw, cn, ksize, sgn, prologue,
-                                     groups, eps, int(narrow.dtype == F32), ns, dw_strides[0], dw_strides[1],
+                                     groups, eps, int(narrow.dtype == F32), int(wide.dtype == F16), ns, dw_strides[0],
+                                     dw_strides[1],
                                      dw_strides[2], _ptr(ws), ws.numel() * 4, _stream()), "pti_wgrad_direct")
     return dw
 
@@ -214,7 +220,7 @@ def wgrad_workspace(device, nbytes=48 << 20):
 
 def conv_wgrad_mfma(x, dy, dw, dbias, *, ksize=3, mode=PTI_CONV_S1, prologue=PTI_PRO_NONE, in_stats=None, gamma=None,
                     beta=None, groups=0, eps=1e-6, accumulate=False, workspace=None):
-    _chk(x, BF16, "x", 4)
+    _chk(x, ACT16, "x", 4)
     _chk(dy, BF16, "dy", 4)
     _chk(dw, F32, "dw")
     n, h, w, cin = x.shape
@@ -235,7 +241,7 @@ def conv_wgrad_mfma(x, dy, dw, dbias, *, ksize=3, mode=PTI_CONV_S1, prologue=PTI
                 raise ValueError(f"conv_wgrad_mfma: {nm} size")
     ws = workspace if workspace is not None else wgrad_workspace(x.device)
     d = ConvDesc(n=n, h=h, w=w, cin=cin, ho=ho, wo=wo, cout=cout, ksize=ksize, mode=mode, prologue=prologue,
-                 groups=groups, eps=eps)
+                 groups=groups, eps=eps, in_f16=int(x.dtype == F16))
     prof = KERNEL_PROFILE
     if prof is None:
         L.check(L.lib().pti_conv_wgrad_mfma(_ptr(x), _ptr(dy), _ptr(in_stats), _ptr(gamma), _ptr(beta), _ptr(dw),
@@ -271,7 +277,7 @@ def _wgrad_kernel_name(ksize, mode, cin, cout, ntiles):
 
 def gn_bwd(x, da, dx, stats, gamma, beta, sums, dgamma, dbeta, *, groups, eps=1e-6, silu=True, dres=None):
     """dx <- backward of act(GroupNorm(x)); ``sums`` is a ZEROED fp32 [n,c,2] scratch."""
-    _chk(x, BF16, "x", 4)
+    _chk(x, ACT16, "x", 4)
     _chk(da, BF16, "da", 4)
     _chk(dx, BF16, "dx", 4)
     n, h, w, c = x.shape
@@ -280,8 +286,8 @@ def gn_bwd(x, da, dx, stats, gamma, beta, sums, dgamma, dbeta, *, groups, eps=1e
     if sums.numel() != n * c * 2 or stats.numel() != n * groups * 2:
         raise ValueError("gn_bwd: scratch sizes")
     L.check(L.lib().pti_gn_bwd(_ptr(x), _ptr(da), _ptr(dres), _ptr(dx), _ptr(stats), _ptr(gamma), _ptr(beta),
-                               _ptr(sums), _ptr(dgamma), _ptr(dbeta), n, h * w, c, groups, eps, int(silu), _stream()),
-            "pti_gn_bwd")
+                               _ptr(sums), _ptr(dgamma), _ptr(dbeta), n, h * w, c, groups, eps, int(silu),
+                               int(x.dtype == F16), _stream()), "pti_gn_bwd")
     return dx
 
 
@@ -290,7 +296,7 @@ def conv_mfma_gnbwd(dy_in, w_packed_t, gx, gstats, ggamma, gbeta, dy_out, gsums,
     """Data-gradient conv with the GroupNorm(+SiLU) backward reduction fused into its epilogue:
     dy_out = conv^T(dy_in) * act'(GN(gx)); gsums[n,c] += {sum dy_out, sum dy_out*xhat} (gsums zeroed by caller)."""
     _chk(dy_in, BF16, "dy_in", 4)
-    _chk(gx, BF16, "gx", 4)
+    _chk(gx, ACT16, "gx", 4)
     _chk(dy_out, BF16, "dy_out", 4)
     n, h, w, cin = dy_in.shape
     ho, wo = conv_out_hw(h, w, mode)
@@ -298,7 +304,8 @@ def conv_mfma_gnbwd(dy_in, w_packed_t, gx, gstats, ggamma, gbeta, dy_out, gsums,
         raise ValueError("conv_mfma_gnbwd: shapes")
     if gsums.numel() != n * cout * 2 or gstats.numel() != n * groups * 2 or ggamma.numel() != cout:
         raise ValueError("conv_mfma_gnbwd: GroupNorm buffers")
-    d = ConvDesc(n=n, h=h, w=w, cin=cin, ho=ho, wo=wo, cout=cout, ksize=ksize, mode=mode, groups=groups, eps=eps)
+    d = ConvDesc(n=n, h=h, w=w, cin=cin, ho=ho, wo=wo, cout=cout, ksize=ksize, mode=mode, groups=groups, eps=eps,
+                 res_f16=int(gx.dtype == F16))
     prof = KERNEL_PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -315,15 +322,15 @@ def conv_mfma_gnbwd(dy_in, w_packed_t, gx, gstats, ggamma, gbeta, dy_out, gsums,
 
 
 def gn_bwd_apply(x, dy, dx, stats, gamma, beta, sums, dgamma, dbeta, *, groups, eps=1e-6, dres=None):
-    _chk(x, BF16, "x", 4)
+    _chk(x, ACT16, "x", 4)
     _chk(dy, BF16, "dy", 4)
     _chk(dx, BF16, "dx", 4)
     n, h, w, c = x.shape
     if dy.shape != x.shape or dx.shape != x.shape or (dres is not None and dres.shape != x.shape):
         raise ValueError("gn_bwd_apply: shape mismatch")
     L.check(L.lib().pti_gn_bwd_apply(_ptr(x), _ptr(dy), _ptr(dres), _ptr(dx), _ptr(stats), _ptr(gamma), _ptr(beta),
-                                     _ptr(sums), _ptr(dgamma), _ptr(dbeta), n, h * w, c, groups, eps, _stream()),
-            "pti_gn_bwd_apply")
+                                     _ptr(sums), _ptr(dgamma), _ptr(dbeta), n, h * w, c, groups, eps,
+                                     int(x.dtype == F16), _stream()), "pti_gn_bwd_apply")
     return dx
 
 

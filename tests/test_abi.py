@@ -28,11 +28,20 @@ def test_header_symbols_are_bound_and_exported():
     assert handle.pti_abi_version() == 1
 
 
-def test_conv_desc_layout_matches_header():
+def test_conv_desc_layout_matches_header(tmp_path):
+    """ctypes mirror vs the C compiler's view of include/pti_vae.h (sizeof + every field offset)."""
+    import subprocess
     from pti_ldm_vae_amd._lib import ConvDesc
-    # 15 int32/float fields + 2 int32 + 8 int64, 8-byte aligned
-    assert C.sizeof(ConvDesc) == 17 * 4 + 4 + 8 * 8
-    assert ConvDesc.in_stride.offset == 72 and ConvDesc.out_stride.offset == 104
+    fields = [f[0] for f in ConvDesc._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "pti_vae.h"\nint main(void){printf("%zu", sizeof(pti_conv_desc));'
+                   + "".join(f'printf(" %zu", offsetof(pti_conv_desc, {f}));' for f in fields) + "return 0;}\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    vals = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert C.sizeof(ConvDesc) == vals[0]
+    assert [getattr(ConvDesc, f).offset for f in fields] == vals[1:]
+    assert ConvDesc.in_stride.offset == 72 and ConvDesc.out_stride.offset == 104 and ConvDesc.in_f16.offset == 136
 
 
 def test_validation_errors_before_launch():

@@ -1,9 +1,12 @@
-"""Model-level GPU parity: the HIP VAEModel (bf16 storage / MFMA, fp32 accumulate) against the CPU
-fp32 oracle on identical weights, inputs and eps.
+"""Model-level GPU parity: the HIP VAEModel (bf16 MFMA operands, fp32 accumulate, fp16-stored forward
+activations) against the CPU fp32 oracle on identical weights, inputs and eps.
 
 Stated tolerances (BASELINE.json / SURVEY.md §8d):
-  * sampled-forward reconstruction: per-pixel MSE <= 1e-4 (target of north_star); measured values are
-    printed — the floor set by bf16 operand rounding alone is ~7e-5 on this random-init network;
+  * reconstruction of the forward pass with the shared eps: per-pixel MSE <= 1e-4 (target of north_star);
+    measured 4.7e-5 (A@64), 5.1e-5 (AR@64), 5.0e-5 (A@256) -- the remainder is bf16 rounding of the MFMA
+    operands (with bf16-stored activations it was 9.2e-5 .. 1.04e-4).  The eps-free reconstruction decode(mu)
+    is printed too (1.2e-4 .. 2.1e-4: the decoder amplifies the encoder's 1e-2 relative error ~3x when no
+    sampling noise dominates z); it is reported, not gated;
   * z_mu and log(sigma): relative L2 <= 2e-2;
   * one training step: loss scalars within 1e-2 relative, whole-gradient cosine >= 0.995,
     per-tensor cosine >= 0.98 for every tensor with >= 1024 elements.
@@ -67,11 +70,8 @@ def test_forward_parity(dev, tag, batch, size):
     assert rec.shape == x.shape and mu.shape == eps.shape
     assert _rel(mu, mu_o) <= 2e-2
     assert _rel(sig.log(), sig_o.log()) <= 2e-2
-    # 64x64 cases meet the 1e-4 target; the all-bf16-storage 256x256 case sits AT it (measured 1.04e-4 in
-    # round 1: bf16 operand rounding alone is 6.7e-5) -> bounded at 1.2e-4 here, see DESIGN.md 'Precision'.
-    # NOTE round 1: float-atomic GroupNorm statistics make the result vary run to run by ~+-10 % in MSE
-    # (9.2e-5 .. 1.05e-4 observed for A@64), so the gate is 1.5e-4 until the fp32 low-resolution stream lands.
-    assert mse <= 1.5e-4
+    # float-atomic GroupNorm statistics move the value by a few % run to run; 2x margin to the target
+    assert mse <= 1e-4
 
 
 def test_golden_vectors_A64(dev):
@@ -83,7 +83,7 @@ def test_golden_vectors_A64(dev):
     assert float(x.double().sum()) == pytest.approx(float(g["x_sum"]), rel=1e-9)
     with torch.no_grad():
         rec, mu, sig = _fwd_hip(model, x.to(dev), eps.to(dev))
-    assert ((rec.cpu() - torch.from_numpy(g["recon"])) ** 2).mean().item() <= 1.5e-4
+    assert ((rec.cpu() - torch.from_numpy(g["recon"])) ** 2).mean().item() <= 1e-4
     assert _rel(mu.cpu(), torch.from_numpy(g["mu"])) <= 2e-2
     assert _rel(sig.cpu(), torch.from_numpy(g["sigma"])) <= 2e-2
 
