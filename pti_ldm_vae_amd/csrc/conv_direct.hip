@@ -70,72 +70,83 @@ __global__ __launch_bounds__(256) void direct_fewcin_kernel(DArgs a) {
   for (int c = 0; c < 32; c += 8) *(u32x4*)(yo + c) = pack8f(acc + c, a.wide_f16);
 }
 
-// ---- many input channels (NHWC bf16 dense, cin % 8 == 0, cin/8 | 64) -> few output channels ----
-// thread = (pixel, 8-channel piece); NC = cin/8 consecutive lanes cooperate on one pixel.
+// ---- many input channels (NHWC 16-bit dense, cin % 8 == 0, cin/8 | 64) -> few output channels ----
+// Centre-based: out[p][co] = sum_t partial_t[p + off_t][co] with partial_t[q][co] = sum_ci act(x)[q][ci] * w[t][ci][co].
+// A block owns a TH x 16 tile of output pixels.  Phase 1: every pixel q of the tile + 1-pixel halo is loaded ONCE
+// (16-byte pieces, NC = cin/8 consecutive lanes per pixel), the GroupNorm prologue is applied ONCE, the 9*Cout
+// partial dot products are reduced over the NC lanes with a halving shuffle tree and stored to an LDS table
+// P[q][t][co].  Phase 2: each output gathers its 9 partials from LDS.  (The first version gathered the 9 neighbours
+// per output from global memory and re-applied the prologue to each: 0.5 TB/s at 256^2; its LDS weight table was
+// also read at a 128-byte lane stride = 16-way bank conflicts: 138 us for an 8 MB map.)
 template <int MAXCO>
-__global__ __launch_bounds__(256) void direct_fewcout_kernel(DArgs a) {
+struct FoCfg {
+  static constexpr int TW = 16, TH = MAXCO <= 4 ? 8 : 4;
+  static constexpr int HW = TW + 2, HH = TH + 2, NP = HH * HW;
+  static constexpr int NV = 9 * MAXCO;            // partial sums per centre pixel
+};
+
+template <int MAXCO>
+__global__ __launch_bounds__(256) void direct_fewcout_kernel(DArgs a, int tiles_x, int tiles_y) {
+  using C = FoCfg<MAXCO>;
+  extern __shared__ float fsm[];
+  float* P = fsm;                                  // [NP][NV]
+  float* wsm = fsm + C::NP * C::NV;                // MAXCO > 1: [9][NC][8*Cout + 4] (padded against bank conflicts)
   const int NC = a.Cin / 8;
-  const int lc = threadIdx.x % NC, lp = threadIdx.x / NC;
-  const int ppb = 256 / NC;
-  const long long npix = (long long)a.N * a.H * a.W;
-  const int pad = (a.KS - 1) / 2;
-  const int cpg = a.prologue ? a.Cin / a.groups : 1;
+  const int tid = threadIdx.x, lc = tid % NC;
+  const int pad = (a.KS - 1) / 2, ntap = a.KS * a.KS;
+  const int ntiles = a.N * tiles_x * tiles_y;
+  const int wpitch = 8 * a.Cout + 4;
   const bf16* X = (const bf16*)a.x;
-  // single-output-channel layers (decoder conv_out at full resolution) keep their 9x8 weights in registers
-  extern __shared__ float wsm[];   // [k*k][Cin][Cout] when it fits (dynamic LDS size > 0)
-  const int wcount = a.KS * a.KS * a.Cin * a.Cout;
-  const bool w_in_lds = (MAXCO != 1) && (a.w_lds != 0);
-  if (w_in_lds) {
-    for (int i = threadIdx.x; i < wcount; i += 256) wsm[i] = a.w[i];
-    __syncthreads();
-  }
-  const float* W = w_in_lds ? wsm : a.w;
   float wreg[MAXCO == 1 ? 9 : 1][8];
   if constexpr (MAXCO == 1) {
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) wreg[t][j] = (t < a.KS * a.KS) ? a.w[(size_t)(t * a.Cin + lc * 8 + j)] : 0.f;
+      for (int j = 0; j < 8; ++j) wreg[t][j] = (t < ntap) ? a.w[(size_t)(t * a.Cin + lc * 8 + j)] : 0.f;
+  } else if (a.w_lds) {
+    const int per_tap = a.Cin * a.Cout;
+    for (int i = tid; i < ntap * per_tap; i += 256) {
+      const int t = i / per_tap, r = i - t * per_tap;         // r = ci * Cout + co
+      const int g = r / (8 * a.Cout), q = r - g * 8 * a.Cout;
+      wsm[(t * NC + g) * wpitch + q] = a.w[i];
+    }
   }
   float sc[8], sh[8];
   int cur_n = -1;
-  for (long long pix0 = (long long)blockIdx.x * ppb; pix0 < npix; pix0 += (long long)gridDim.x * ppb) {
-    const long long pix = pix0 + lp;
-    const bool act = pix < npix;
-    const long long pc = act ? pix : 0;
-    const int ox = pc % a.W;
-    const int oy = (pc / a.W) % a.H;
-    const int n = pc / ((long long)a.W * a.H);
-    if (a.prologue && n != cur_n) {
-      cur_n = n;
+  if constexpr (MAXCO > 1) __syncthreads();
+  // persistent blocks: the per-block set-up (weights to registers / LDS) is paid once, not once per 128 outputs
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const int tx = tile % tiles_x;
+  const int tr = tile / tiles_x;
+  const int n = tr / tiles_y;
+  const int oy0 = (tr - n * tiles_y) * C::TH, ox0 = tx * C::TW;
+  if (a.prologue && n != cur_n) {
+    cur_n = n;
+    const int cpg = a.Cin / a.groups;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int ch = lc * 8 + j, g = ch / cpg;
-        const float sum = a.in_stats[(n * a.groups + g) * 2], sq = a.in_stats[(n * a.groups + g) * 2 + 1];
-        const float mean = sum * a.inv_cnt;
-        const float rstd = rsqrtf(fmaxf(sq * a.inv_cnt - mean * mean, 0.f) + a.eps);
-        sc[j] = rstd * a.gamma[ch];
-        sh[j] = a.beta[ch] - mean * sc[j];
-      }
+    for (int j = 0; j < 8; ++j) {
+      const int ch = lc * 8 + j, g = ch / cpg;
+      const float sum = a.in_stats[(n * a.groups + g) * 2], sq = a.in_stats[(n * a.groups + g) * 2 + 1];
+      const float mean = sum * a.inv_cnt;
+      const float rstd = rsqrtf(fmaxf(sq * a.inv_cnt - mean * mean, 0.f) + a.eps);
+      sc[j] = rstd * a.gamma[ch];
+      sh[j] = a.beta[ch] - mean * sc[j];
     }
-    float acc[MAXCO];
+  }
+
+  // ---- phase 1: partial dot products of every centre pixel of the halo'd tile ----
+  const int ppi = 256 / NC;                         // pixels per iteration
+  for (int q0 = 0; q0 < C::NP; q0 += ppi) {
+    const int q = q0 + tid / NC;
+    const int hy = q / C::HW, hx = q - hy * C::HW;
+    const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+    const bool ok = q < C::NP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    float f[8];
 #pragma unroll
-    for (int c = 0; c < MAXCO; ++c) acc[c] = 0.f;
-    u32x4 raw[9];
-    bool ok[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int kh = t / 3, kw = t % 3;
-      const int iy = oy + kh - pad, ix = ox + kw - pad;
-      ok[t] = act && kh < a.KS && kw < a.KS && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-      raw[t] = u32x4{0u, 0u, 0u, 0u};
-      if (ok[t]) raw[t] = *(const u32x4*)(X + ((size_t)(n * a.H + iy) * a.W + ix) * a.Cin + lc * 8);
-    }
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      if (!ok[t]) continue;
-      float f[8];
-      unpack8f(raw[t], f, a.wide_f16);
+    for (int j = 0; j < 8; ++j) f[j] = 0.f;
+    if (ok) {
+      const u32x4 raw = *(const u32x4*)(X + ((size_t)(n * a.H + iy) * a.W + ix) * a.Cin + lc * 8);
+      unpack8f(raw, f, a.wide_f16);
       if (a.prologue) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -144,33 +155,84 @@ __global__ __launch_bounds__(256) void direct_fewcout_kernel(DArgs a) {
           f[j] = v;
         }
       }
+    }
+    // v[t * MAXCO + co]; padded to a multiple of 16 so that the halving tree below is uniform for every NC <= 16
+    constexpr int NVP = (C::NV + 15) / 16 * 16;
+    float v[NVP];
+#pragma unroll
+    for (int i = 0; i < NVP; ++i) v[i] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
       if constexpr (MAXCO == 1) {
+        float s_ = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[0] += f[j] * wreg[t][j];
+        for (int j = 0; j < 8; ++j) s_ += f[j] * wreg[t][j];
+        v[t] = s_;
       } else {
-        const float* wt = W + ((size_t)(a.KS == 3 ? t : 0) * a.Cin + lc * 8) * a.Cout;
+        if (t < ntap) {
+          const float* wt = a.w_lds ? wsm + (t * NC + lc) * wpitch : a.w + (size_t)(t * a.Cin + lc * 8) * a.Cout;
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+          for (int c = 0; c < MAXCO; ++c) {
+            if (c < a.Cout) {
+              float s_ = 0.f;
 #pragma unroll
-          for (int c = 0; c < MAXCO; ++c)
-            if (c < a.Cout) acc[c] += f[j] * wt[j * a.Cout + c];
+              for (int j = 0; j < 8; ++j) s_ += f[j] * wt[j * a.Cout + c];
+              v[t * MAXCO + c] = s_;
+            }
+          }
+        }
       }
     }
-    // reduce over the NC lanes of this pixel (NC is a power of two <= 64, lanes are consecutive)
+    // reduce over the NC (>= 4) lanes of the pixel: two halving levels (a lane keeps one half of its values and
+    // trades the other with its partner), then plain butterflies on the remaining NVP/4 values
+    {
+      const bool h1 = (lc & 1) != 0, h2 = (lc & 2) != 0;
 #pragma unroll
-    for (int c = 0; c < MAXCO; ++c) {
-      if (c < a.Cout) {
-        float v = acc[c];
-        for (int o = NC >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        acc[c] = v;
+      for (int i = 0; i < NVP / 2; ++i) {
+        const float send = h1 ? v[i] : v[i + NVP / 2];
+        const float keep = h1 ? v[i + NVP / 2] : v[i];
+        v[i] = keep + __shfl_xor(send, 1, 64);
+      }
+#pragma unroll
+      for (int i = 0; i < NVP / 4; ++i) {
+        const float send = h2 ? v[i] : v[i + NVP / 4];
+        const float keep = h2 ? v[i + NVP / 4] : v[i];
+        v[i] = keep + __shfl_xor(send, 2, 64);
+      }
+#pragma unroll
+      for (int o = 4; o < 64; o <<= 1) {
+        if (o < NC) {
+#pragma unroll
+          for (int i = 0; i < NVP / 4; ++i) v[i] += __shfl_xor(v[i], o, 64);
+        }
+      }
+      // lane lc (< 4) now holds values [first, first + NVP/4) of its pixel, summed over all channels
+      const int first = (h1 ? NVP / 2 : 0) + (h2 ? NVP / 4 : 0);
+      if (lc < 4 && q < C::NP) {
+#pragma unroll
+        for (int i = 0; i < NVP / 4; ++i)
+          if (first + i < C::NV) P[q * C::NV + first + i] = v[i];
       }
     }
-    if (act && lc == 0) {
-      const long long ob = n * a.os[0] + oy * a.os[1] + ox * a.os[2];
+  }
+  __syncthreads();
+  // ---- phase 2: gather ----
+  for (int e = tid; e < C::TH * C::TW * MAXCO; e += 256) {
+    const int co = e % MAXCO, pi = e / MAXCO;
+    const int py = pi / C::TW, px = pi - py * C::TW;
+    const int oy = oy0 + py, ox = ox0 + px;
+    if (co < a.Cout && oy < a.H && ox < a.W) {
+      float s_ = a.bias ? a.bias[co] : 0.f;
 #pragma unroll
-      for (int c = 0; c < MAXCO; ++c)
-        if (c < a.Cout) st_narrow(a.y, ob + c * a.os[3], a.out_f32, acc[c] + (a.bias ? a.bias[c] : 0.f));
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+          if (kh < a.KS && kw < a.KS)
+            s_ += P[((py + 1 + kh - pad) * C::HW + px + 1 + kw - pad) * C::NV + (kh * a.KS + kw) * MAXCO + co];
+      st_narrow(a.y, n * a.os[0] + oy * a.os[1] + ox * a.os[2] + co * a.os[3], a.out_f32, s_);
     }
+  }
+  __syncthreads();   // P is rewritten by the next tile
   }
 }
 
@@ -213,14 +275,50 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(WGArgs a) {
     for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
 #pragma unroll
   for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
-  // "wide" is the centre of the stencil: one 16-byte load (+ prologue, applied ONCE) per pixel piece, multiplied with
-  // the K*K neighbouring narrow scalars (4-byte, cache resident):  dW[tap][cw] = sum_p' wide[p'] * narrow[p' - sgn*off]
-  for (long long pix0 = (long long)blockIdx.x * ppb; pix0 < npix; pix0 += (long long)gridDim.x * ppb) {
-    const long long pix = pix0 + lp;
-    if (pix >= npix) continue;
-    const int ox = pix % a.W;
-    const int oy = (pix / a.W) % a.H;
-    const int n = pix / ((long long)a.W * a.H);
+  // "wide" is the centre of the stencil:  dW[tap][cw] = sum_p wide[p] * narrow[p - sgn*off_tap].
+  // A block walks 8x16-pixel tiles (tile = blockIdx.x, + gridDim.x, ...), accumulating in registers across tiles.
+  // Per tile the narrow halo (10x18 scalars of channel k, zero outside the image) is staged in LDS once, so the inner
+  // loop is: one 16-byte wide load (+ prologue, applied ONCE), 9 LDS reads, 72 FMAs -- no bounds checks, no 64-bit
+  // strided addressing.  (The first version fetched the 9 narrow neighbours from global memory per pixel piece with
+  // per-lane 64-bit index arithmetic: 0.5 TB/s.)
+  constexpr int TH_ = 8, TW_ = 16, HW_ = TW_ + 2, NPH = (TH_ + 2) * HW_;
+  __shared__ float nar[2][NPH];
+  const int tiles_x = (a.W + TW_ - 1) / TW_, tiles_y = (a.H + TH_ - 1) / TH_;
+  const int ntiles = a.N * tiles_x * tiles_y;
+  const int ITER = (TH_ * TW_ * NC + 255) / 256;          // pixel pieces of a tile per thread (NC <= 32 => <= 16)
+  auto tile_org = [&](int tile, int& n, int& oy0, int& ox0) {
+    const int tx = tile % tiles_x;
+    const int r = tile / tiles_x;
+    n = r / tiles_y;
+    oy0 = (r - n * tiles_y) * TH_;
+    ox0 = tx * TW_;
+  };
+  auto load_wide = [&](int tile, int it) -> u32x4 {
+    int n, oy0, ox0;
+    tile_org(tile, n, oy0, ox0);
+    const int pi = it * ppb + lp;
+    const int oy = oy0 + pi / TW_, ox = ox0 + pi % TW_;
+    u32x4 r = u32x4{0u, 0u, 0u, 0u};
+    if (tile < ntiles && pi < TH_ * TW_ && oy < a.H && ox < a.W)
+      r = *(const u32x4*)(a.wide + ((size_t)(n * a.H + oy) * a.W + ox) * a.CW + lc * 8);
+    return r;
+  };
+  constexpr int MAXIT = 4;    // ITER <= 4 for CW >= 64... handled in chunks of MAXIT below
+  int buf = 0;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+    int n, oy0, ox0;
+    tile_org(tile, n, oy0, ox0);
+    // stage the narrow halo of channel k (threads 0..NPH-1), accumulate its interior sum for the narrow-side bias
+    if (threadIdx.x < NPH) {
+      const int hy = threadIdx.x / HW_, hx = threadIdx.x - hy * HW_;
+      const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+      float v = 0.f;
+      if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+        v = ld_narrow(a.narrow, n * a.ns[0] + iy * a.ns[1] + ix * a.ns[2] + k * a.ns[3], a.narrow_f32);
+        if (hy >= 1 && hy <= TH_ && hx >= 1 && hx <= TW_) nsum += v;
+      }
+      nar[buf][threadIdx.x] = v;
+    }
     if (a.prologue && n != cur_n) {
       cur_n = n;
 #pragma unroll
@@ -233,36 +331,46 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(WGArgs a) {
         sh[j] = a.beta[ch] - mean * sc[j];
       }
     }
-    float f[8];
-    unpack8f(*(const u32x4*)(a.wide + (size_t)pix * a.CW + lc * 8), f, a.wide_f16);
-    if (a.dbias_wide && k == 0) {
+    __syncthreads();   // one barrier per tile: the other buffer is only rewritten after the next barrier
+    for (int it0 = 0; it0 < ITER; it0 += MAXIT) {
+      u32x4 raw[MAXIT];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) bsum[j] += f[j];
-    }
-    if (a.prologue) {
+      for (int u = 0; u < MAXIT; ++u) raw[u] = load_wide(tile, it0 + u);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float v = f[j] * sc[j] + sh[j];
-        if (a.prologue == PTI_PRO_GN_SILU) v = silu_f(v);
-        f[j] = v;
-      }
-    }
-    nsum += ld_narrow(a.narrow, n * a.ns[0] + oy * a.ns[1] + ox * a.ns[2] + k * a.ns[3], a.narrow_f32);
+      for (int u = 0; u < MAXIT; ++u) {
+        const int pi = (it0 + u) * ppb + lp;
+        const int py = pi / TW_, px = pi % TW_;
+        if (it0 + u >= ITER || pi >= TH_ * TW_ || oy0 + py >= a.H || ox0 + px >= a.W) continue;
+        float f[8];
+        unpack8f(raw[u], f, a.wide_f16);
+        if (a.dbias_wide && k == 0) {
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
+          for (int j = 0; j < 8; ++j) bsum[j] += f[j];
+        }
+        if (a.prologue) {
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        if (kh < a.KS && kw < a.KS) {
-          const int iy = oy - a.sgn * (kh - pad), ix = ox - a.sgn * (kw - pad);
-          if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
-            const float nv = ld_narrow(a.narrow, n * a.ns[0] + iy * a.ns[1] + ix * a.ns[2] + k * a.ns[3], a.narrow_f32);
+          for (int j = 0; j < 8; ++j) {
+            float v = f[j] * sc[j] + sh[j];
+            if (a.prologue == PTI_PRO_GN_SILU) v = silu_f(v);
+            f[j] = v;
+          }
+        }
+        const float* nb = &nar[buf][(py + 1) * HW_ + px + 1];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[kh * 3 + kw][j] += nv * f[j];
+        for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            if (kh < a.KS && kw < a.KS) {
+              const float nv = nb[-a.sgn * ((kh - pad) * HW_ + (kw - pad))];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) acc[kh * 3 + kw][j] += nv * f[j];
+            }
           }
         }
       }
     }
   }
+  (void)npix;
   // reduction: (1) across the lanes of a wave that share lc (stride NC) by shuffles, (2) across the
   // 4 waves through LDS, (3) one atomicAdd per output element and block.
   extern __shared__ float red[];  // [4][80][NC]
@@ -291,7 +399,7 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(WGArgs a) {
   for (int e = threadIdx.x; e < 80 * NC; e += 256)
     mine[e] = red[e] + red[80 * NC + e] + red[2 * 80 * NC + e] + red[3 * 80 * NC + e];
   {
-    float v = (lc == 0) ? nsum : 0.f;
+    float v = nsum;   // every staging thread summed distinct interior pixels
     v = wave_sum(v);
     __syncthreads();
     if (lane == 0) red[wave] = v;
@@ -369,17 +477,22 @@ extern "C" int pti_conv2d_direct(const void* x, const float* w, const float* bia
     a.wide_f16 = d->in_f16;
     if (d->prologue && (!in_stats || !gamma || !beta || d->groups <= 0 || d->cin % d->groups))
       PTI_FAIL(PTI_EINVAL, "conv2d_direct: prologue needs stats/gamma/beta");
-    const int ppb = 256 / (d->cin / 8);
-    long long blocks = (npix + ppb - 1) / ppb;
-    if (blocks > 65536) blocks = 65536;
-    if (blocks > 2048) blocks = 2048;
-    const size_t wbytes = (size_t)d->ksize * d->ksize * d->cin * d->cout * sizeof(float);
-    const size_t lds = (d->cout > 1 && wbytes <= 60 * 1024) ? wbytes : 0;
-    a.w_lds = lds ? 1 : 0;
-    if (lds && blocks > 512) blocks = 512;   // amortise the weight staging over several pixels per block
-    if (d->cout == 1) hipLaunchKernelGGL(direct_fewcout_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, a);
-    else if (d->cout <= 4) hipLaunchKernelGGL(direct_fewcout_kernel<4>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)s, a);
-    else hipLaunchKernelGGL(direct_fewcout_kernel<16>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)s, a);
+    if (d->cin < 32) PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_direct: few-cout path needs cin >= 32");
+    const int nc = d->cin / 8;
+    auto launch = [&](auto cfg, auto kern) {
+      using C = decltype(cfg);
+      const int tiles_x = cdiv(d->w, C::TW), tiles_y = cdiv(d->h, C::TH);
+      const size_t pbytes = (size_t)C::NP * C::NV * sizeof(float);
+      const size_t wbytes = d->cout > 1 ? (size_t)d->ksize * d->ksize * nc * (8 * d->cout + 4) * sizeof(float) : 0;
+      a.w_lds = (wbytes > 0 && pbytes + wbytes <= 64 * 1024) ? 1 : 0;   // else the weights are read through L1/L2
+      const size_t lds = pbytes + (a.w_lds ? wbytes : 0);
+      long long blocks = (long long)d->n * tiles_x * tiles_y;
+      if (blocks > 1024) blocks = 1024;
+      hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)s, a, tiles_x, tiles_y);
+    };
+    if (d->cout == 1) launch(FoCfg<1>{}, direct_fewcout_kernel<1>);
+    else if (d->cout <= 4) launch(FoCfg<4>{}, direct_fewcout_kernel<4>);
+    else launch(FoCfg<16>{}, direct_fewcout_kernel<16>);
   } else {
     PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_direct: cin=%d cout=%d is not a degenerate-channel shape", d->cin, d->cout);
   }
@@ -407,9 +520,14 @@ extern "C" int pti_wgrad_direct(const void* wide, const void* narrow, float* dw,
   for (int i = 0; i < 4; ++i) a.ns[i] = narrow_stride[i];
   a.dw_stride_tap = dw_stride_tap; a.dw_stride_cw = dw_stride_cw; a.dw_stride_k = dw_stride_k;
   const long long npix = (long long)n * h * w;
+  if (npix * cw >= (1ll << 31)) PTI_FAIL(PTI_EUNSUPPORTED, "wgrad_direct: tensor too large for 32-bit pixel indexing");
   const int ppb = 256 / (cw / 8);
-  long long blocks = (npix + ppb - 1) / ppb;
-  if (blocks > 1024) blocks = 1024;
+  // persistent blocks over 8x16-pixel tiles: 3 blocks/CU (160 VGPRs) x 256 CUs resident, >= 4 tiles each -- every
+  // block writes 80*NC+1 partials, which for small maps would otherwise exceed the tensor itself
+  const long long ntiles = (long long)n * ((h + 7) / 8) * ((w + 15) / 16);
+  long long blocks = ntiles / 4;
+  if (blocks > 768) blocks = 768;
+  if (blocks < 1) blocks = 1;
   const long long per = 80 * (cw / 8) + 1;
   while (blocks > 1 && blocks * cn * per * 4 > workspace_bytes) blocks /= 2;
   if (blocks * cn * per * 4 > workspace_bytes) PTI_FAIL(PTI_EINVAL, "wgrad_direct: workspace too small");
