@@ -417,7 +417,12 @@ struct Cfg2 {
   static constexpr int ENC = CT / 8;                      // 16-byte pieces per pixel of the tile
   static constexpr int EITERS = MPX * ENC / 256;
   static constexpr int STAT_OFF = HALO_BYTES > EPI_BYTES ? HALO_BYTES : EPI_BYTES;   // 256 floats of group sums
-  static constexpr int LDS_BYTES = STAT_OFF + 1024;
+  // residual tile (or the GroupNorm input of the fused backward): its own LDS region, filled by LDS-DMA
+  // (global_load_lds_dwordx4, no registers) at kernel start so that it shares the halo loads' round trip instead of
+  // costing a second one in the epilogue.  Lane-linear image [pixel][CT/8 pieces], swizzled on the SOURCE side.
+  static constexpr int RT_OFF = STAT_OFF + 1024;
+  static constexpr int RT_BYTES = MPX * CT * 2;
+  static constexpr int LDS_BYTES = RT_OFF + RT_BYTES;
 };
 
 template <int KS, int CK, int CT, int PXF, bool SAVE>
@@ -463,6 +468,23 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
   constexpr int PSTEP = 256 / C::NC;
   const int cpg = a.Cin / (a.groups > 0 ? a.groups : 1);
   reinterpret_cast<float*>(smem + C::STAT_OFF)[tid] = 0.f;   // visible after the first barrier below
+  if (a.res) {
+    // piece (p, c) of the residual tile -> LDS slot p*ENC + c, holding channel piece c ^ ((p >> 2) & (ENC-1)) (the
+    // epilogue reads apply the same XOR: 8-byte reads of one piece column at a 64..256-byte pixel pitch would
+    // otherwise hit the same banks).  Out-of-image pixels are skipped (their slots are never used for output).
+#pragma unroll
+    for (int it = 0; it < C::EITERS; ++it) {
+      const int slot = it * 256 + tid;
+      const int p = slot / C::ENC, c = slot % C::ENC;
+      const int oy = oy0 + p / C::TW2, ox = ox0 + p % C::TW2;
+      if (oy < a.Ho && ox < a.Wo) {
+        const bf16* src = a.res + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.Cout + ct * CT + ((c ^ ((p >> 2) & (C::ENC - 1))) << 3);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(smem + C::RT_OFF + (it * 256 + wave * 64) * 16),
+                                         16, 0, 0);
+      }
+    }
+  }
 
   // (tried: fetching the residual tile to registers under the last chunk's MFMA loop -> spills at the
   //  128-VGPR cap of the 4-workgroup/CU shapes, 1.9x slower)
@@ -626,19 +648,8 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
   const bool do_stats = a.out_stats != nullptr;
   const int ocpg = do_stats ? a.Cout / a.out_groups : 1;
   __syncthreads();  // every wave is done with the halo tile
-  // (A) residual tile -> LDS with coalesced 16-byte loads
-  if (a.res) {
-#pragma unroll
-    for (int it = 0; it < C::EITERS; ++it) {
-      const int p = epp0 + it * EPSTEP;
-      const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
-      u32x4 r = u32x4{0u, 0u, 0u, 0u};
-      if (oy < a.Ho && ox < a.Wo)
-        r = *(const u32x4*)(a.res + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.Cout + ct * CT + epc * 8);
-      *(u32x4*)(etile + p * C::EPITCH + epc * 16) = r;
-    }
-    __syncthreads();
-  }
+  // (A) the residual tile is already in LDS (rtile, LDS-DMA issued at kernel start; every barrier since drained it)
+  const unsigned char* rtile = smem + C::RT_OFF;
   const int col0 = wn * 32 + 4 * hsel;   // channel within the CT tile
   float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f};   // per quad q (or first pair when ocpg==2)
   float su1[4] = {0.f, 0.f, 0.f, 0.f}, su2[4] = {0.f, 0.f, 0.f, 0.f};   // second pair of the quad when ocpg==2
@@ -666,7 +677,7 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
         const int p = (2 * PXF * wm + 2 * i + (j >> 4)) * 16 + (j & 15);
         const bool inb = (oy0 + (p >> 4) < a.Ho) && (ox0 + (p & 15) < a.Wo);
         unsigned char* ep = etile + p * C::EPITCH + col * 2;
-        const u32x2 rr = *(const u32x2*)ep;
+        const u32x2 rr = *(const u32x2*)(rtile + p * (CT * 2) + ((((col >> 3) ^ (p >> 2)) & (C::ENC - 1)) << 4) + (col & 7) * 2);
         float xv[4];
         unpack2f(rr[0], a.res_f16, xv[0], xv[1]);
         unpack2f(rr[1], a.res_f16, xv[2], xv[3]);
@@ -714,7 +725,7 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
       }
       unsigned char* ep = etile + p * C::EPITCH + col * 2;
       if (a.res) {
-        const u32x2 rr = *(const u32x2*)ep;
+        const u32x2 rr = *(const u32x2*)(rtile + p * (CT * 2) + ((((col >> 3) ^ (p >> 2)) & (C::ENC - 1)) << 4) + (col & 7) * 2);
         float e0, e1, e2, e3;
         unpack2f(rr[0], a.res_f16, e0, e1);
         unpack2f(rr[1], a.res_f16, e2, e3);
@@ -826,35 +837,41 @@ struct PackArgs {
   long long total;
 };
 
-__device__ __forceinline__ void pack_one(const PackArgs& p, long long e) {
+// one thread packs the 8 consecutive bf16 of one lane's fragment piece (one 16-byte store); 32-bit index math
+__device__ __forceinline__ void pack_eight(const PackArgs& p, int e8) {
   const int NT = p.cout_tile / 32, KPC = p.ck / 16, KBC = p.ks * p.ks * KPC, nch = p.cin_l / p.ck;
-  long long r = e;
-  const int j = r % 8; r /= 8;
+  int r = e8;
   const int lane = r % 64; r /= 64;
   const int nt = r % NT; r /= NT;
   const int kb = r % KBC; r /= KBC;
-  const int chunk = r % nch; r /= nch;
-  const int ct = (int)r;
+  const int chunk = r % nch;
+  const int ct = r / nch;
   const int co = ct * p.cout_tile + nt * 32 + (lane & 31);
   const int tap = kb / KPC, kc = kb % KPC;
-  const int ci = chunk * p.ck + kc * 16 + 8 * (lane >> 5) + j;
+  const int ci0 = chunk * p.ck + kc * 16 + 8 * (lane >> 5);
   const int kk = p.ks * p.ks;
-  float v;
+  const float* src;
+  size_t stride;
   if (!p.flip) {
-    const int s = co / p.cout_o, cs = co % p.cout_o;
-    v = p.src[s][((size_t)cs * p.cin_o + ci) * kk + tap];
+    const int s_ = co / p.cout_o, cs = co % p.cout_o;
+    src = p.src[s_] + ((size_t)cs * p.cin_o + ci0) * kk + tap;
+    stride = kk;
   } else {  // logical co is an original input channel, logical ci an original output channel
-    v = p.src[0][((size_t)ci * p.cin_o + co) * kk + (kk - 1 - tap)];
+    src = p.src[0] + ((size_t)ci0 * p.cin_o + co) * kk + (kk - 1 - tap);
+    stride = (size_t)p.cin_o * kk;
   }
-  p.dst[e] = (bf16)v;
+  float f[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = src[j * stride];
+  *(u32x4*)(p.dst + (size_t)e8 * 8) = pack8(f);
 }
 
 __global__ void pack_weights_kernel(PackArgs p) {
-  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < p.total) pack_one(p, e);
+  const long long e8 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e8 * 8 < p.total) pack_eight(p, (int)e8);
 }
 
-// batched form: table[i] describes one weight, blk_first[i] its first block; blocks are 256 elements
+// batched form: table[i] describes one weight, blk_first[i] its first block; blocks are 256 threads x 8 elements
 __global__ void pack_weights_batched_kernel(const PackArgs* __restrict__ table, const int* __restrict__ blk_first, int n) {
   int lo = 0, hi = n - 1;
   const int b = blockIdx.x;
@@ -863,8 +880,8 @@ __global__ void pack_weights_batched_kernel(const PackArgs* __restrict__ table, 
     if (blk_first[mid] <= b) lo = mid; else hi = mid - 1;
   }
   const PackArgs p = table[lo];
-  const long long e = (long long)(b - blk_first[lo]) * 256 + threadIdx.x;
-  if (e < p.total) pack_one(p, e);
+  const int e8 = (b - blk_first[lo]) * 256 + threadIdx.x;
+  if ((long long)e8 * 8 < p.total) pack_eight(p, e8);
 }
 
 template <int KS, int S, int CK, int COUT_TILE>
@@ -919,7 +936,7 @@ extern "C" int pti_conv_pack_weights(const float* const* w, int nsrc, void* pack
   p.cout_tile = pick_cout_tile(p.cout_l);
   p.ck = (mode == PTI_CONV_S2PAD) ? pick_ck(p.cin_l, true) : pick_ck2(p.cin_l, p.cout_tile);
   p.total = (long long)p.cout_l * p.cin_l * ksize * ksize;
-  const int blocks = (int)((p.total + 255) / 256);
+  const int blocks = (int)((p.total + 2047) / 2048);
   hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, p);
   PTI_CHECK_LAUNCH("pack_weights");
   return PTI_OK;
@@ -952,7 +969,7 @@ extern "C" int pti_conv_pack_table_fill(void* host_entry, const float* w, void* 
   if (fill_pack(p, w, packed, cout, cin, ksize, mode, transpose_flip))
     PTI_FAIL(PTI_EUNSUPPORTED, "pack_table_fill: cout=%d cin=%d k=%d", cout, cin, ksize);
   *(PackArgs*)host_entry = p;
-  *nblocks = (p.total + 255) / 256;
+  *nblocks = (p.total + 2047) / 2048;
   return PTI_OK;
 }
 extern "C" int pti_conv_pack_weights_batched(const void* table_dev, const int* blk_first_dev, int n, int total_blocks,
