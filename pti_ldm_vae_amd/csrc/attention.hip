@@ -57,12 +57,15 @@ __device__ __forceinline__ bf16x8 acc_to_frag(const f32x16& x, int s) {
 }
 
 // cooperative copy of `rows` token rows (D bf16 each) from global (row stride gstride elements) to LDS
+// (rows at or beyond `valid` -- past the end of a token count that is not a multiple of the tile -- are zero-filled)
 template <int D, int NT>
-__device__ __forceinline__ void load_rows(unsigned char* tile, const bf16* src, size_t gstride, int rows, int tid) {
+__device__ __forceinline__ void load_rows(unsigned char* tile, const bf16* src, size_t gstride, int rows, int valid, int tid) {
   constexpr int NC = D / 8;
   for (int e = tid; e < rows * NC; e += NT) {
     const int r = e / NC, c = e % NC;
-    *(u32x4*)(tile + r * ACfg<D>::P + c * 16) = *(const u32x4*)(src + (size_t)r * gstride + c * 8);
+    u32x4 v = u32x4{0u, 0u, 0u, 0u};
+    if (r < valid) v = *(const u32x4*)(src + (size_t)r * gstride + c * 8);
+    *(u32x4*)(tile + r * ACfg<D>::P + c * 16) = v;
   }
 }
 
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const bf16* __restric
   bf16x8 bq[C::KS];
 #pragma unroll
   for (int ks = 0; ks < C::KS; ++ks)
-    bq[ks] = *(const bf16x8*)(base + (size_t)(q0 + (lane & 31)) * rs + 16 * ks + 8 * (lane >> 5));
+    bq[ks] = *(const bf16x8*)(base + (size_t)min(q0 + (lane & 31), L - 1) * rs + 16 * ks + 8 * (lane >> 5));
 
   f32x16 oacc[C::DB];
 #pragma unroll
@@ -93,8 +96,8 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const bf16* __restric
 
   for (int k0 = 0; k0 < L; k0 += C::KT) {
     __syncthreads();
-    load_rows<D, 64 * NW>(sK, base + (size_t)k0 * rs + D, rs, C::KT, tid);
-    load_rows<D, 64 * NW>(sV, base + (size_t)k0 * rs + 2 * D, rs, C::KT, tid);
+    load_rows<D, 64 * NW>(sK, base + (size_t)k0 * rs + D, rs, C::KT, L - k0, tid);
+    load_rows<D, 64 * NW>(sV, base + (size_t)k0 * rs + 2 * D, rs, C::KT, L - k0, tid);
     __syncthreads();
     f32x16 sacc[C::NB];
 #pragma unroll
@@ -113,6 +116,8 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const bf16* __restric
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         sacc[kb][r] *= c_log2;
+        // keys past the end of a ragged sequence (last tile only) take no probability mass
+        if (k0 + C::KT > L && k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) >= L) sacc[kb][r] = -1e30f;
         mt = fmaxf(mt, sacc[kb][r]);
       }
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
@@ -146,6 +151,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const bf16* __restric
   lsum += __shfl_xor(lsum, 32, 64);
   const float inv = 1.f / lsum;
   const int qi = q0 + (lane & 31), h = lane >> 5;
+  if (qi >= L) return;
   bf16* orow = o + ((size_t)b * L + qi) * D;
 #pragma unroll
   for (int d = 0; d < C::DB; ++d)
@@ -196,18 +202,19 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const bf16* __rest
   const size_t rs = 3 * D;
   const bf16* base = qkv + (size_t)b * L * rs;
   const int qi = qb0 + wave * 32 + (lane & 31);
+  const int qc = min(qi, L - 1);   // ragged tail: compute on a clamped row, store nothing
   bf16x8 bq[REGQ ? C::KS : 1], bdo[REGQ ? C::KS : 1];
   if constexpr (REGQ) {
 #pragma unroll
     for (int ks = 0; ks < C::KS; ++ks) {
-      bq[ks] = *(const bf16x8*)(base + (size_t)qi * rs + 16 * ks + 8 * (lane >> 5));
-      bdo[ks] = *(const bf16x8*)(dout + ((size_t)b * L + qi) * D + 16 * ks + 8 * (lane >> 5));
+      bq[ks] = *(const bf16x8*)(base + (size_t)qc * rs + 16 * ks + 8 * (lane >> 5));
+      bdo[ks] = *(const bf16x8*)(dout + ((size_t)b * L + qc) * D + 16 * ks + 8 * (lane >> 5));
     }
   } else {
-    load_rows<D, 64 * NW>(sQ, base + (size_t)qb0 * rs, rs, TB, tid);
-    load_rows<D, 64 * NW>(sDO, dout + ((size_t)b * L + qb0) * D, D, TB, tid);
+    load_rows<D, 64 * NW>(sQ, base + (size_t)qb0 * rs, rs, TB, L - qb0, tid);
+    load_rows<D, 64 * NW>(sDO, dout + ((size_t)b * L + qb0) * D, D, TB, L - qb0, tid);
   }
-  const float my_lse = lse2[(size_t)b * L + qi], my_delta = delta[(size_t)b * L + qi];
+  const float my_lse = lse2[(size_t)b * L + qc], my_delta = delta[(size_t)b * L + qc];
   f32x16 dq[C::DB];
 #pragma unroll
   for (int d = 0; d < C::DB; ++d)
@@ -216,8 +223,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const bf16* __rest
 
   for (int k0 = 0; k0 < L; k0 += C::KT) {
     __syncthreads();
-    load_rows<D, 64 * NW>(sK, base + (size_t)k0 * rs + D, rs, C::KT, tid);
-    load_rows<D, 64 * NW>(sV, base + (size_t)k0 * rs + 2 * D, rs, C::KT, tid);
+    load_rows<D, 64 * NW>(sK, base + (size_t)k0 * rs + D, rs, C::KT, L - k0, tid);
+    load_rows<D, 64 * NW>(sV, base + (size_t)k0 * rs + 2 * D, rs, C::KT, L - k0, tid);
     __syncthreads();
 #pragma unroll
     for (int kb = 0; kb < C::NB; ++kb) {
@@ -234,7 +241,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const bf16* __rest
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = exp2f(sa[r] * c_log2 - my_lse);
+        float p = exp2f(sa[r] * c_log2 - my_lse);
+        if (k0 + C::KT > L && k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) >= L) p = 0.f;   // ragged tail keys
         sa[r] = p * (dp[r] - my_delta) * scale;
       }
 #pragma unroll
@@ -247,6 +255,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const bf16* __rest
     }
   }
   const int h = lane >> 5;
+  if (qi >= L) return;
   bf16* orow = dqkv + ((size_t)b * L + qi) * rs;
 #pragma unroll
   for (int d = 0; d < C::DB; ++d)
@@ -279,15 +288,15 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkdv_kernel(const bf16* __re
   const bf16* base = qkv + (size_t)b * L * rs;
   bf16x8 bk[REGK ? C::KS : 1], bv[REGK ? C::KS : 1];
   if constexpr (REGK) {
-    const bf16* krow = base + (size_t)(kb0 + wave * 32 + (lane & 31)) * rs + 8 * (lane >> 5);
+    const bf16* krow = base + (size_t)min(kb0 + wave * 32 + (lane & 31), L - 1) * rs + 8 * (lane >> 5);
 #pragma unroll
     for (int ks = 0; ks < C::KS; ++ks) {
       bk[ks] = *(const bf16x8*)(krow + D + 16 * ks);
       bv[ks] = *(const bf16x8*)(krow + 2 * D + 16 * ks);
     }
   } else {
-    load_rows<D, 64 * NW>(sK, base + (size_t)kb0 * rs + D, rs, TB, tid);
-    load_rows<D, 64 * NW>(sV, base + (size_t)kb0 * rs + 2 * D, rs, TB, tid);
+    load_rows<D, 64 * NW>(sK, base + (size_t)kb0 * rs + D, rs, TB, L - kb0, tid);
+    load_rows<D, 64 * NW>(sV, base + (size_t)kb0 * rs + 2 * D, rs, TB, L - kb0, tid);
   }
   f32x16 dk[DBL], dv[DBL];
 #pragma unroll
@@ -298,11 +307,13 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkdv_kernel(const bf16* __re
 
   for (int q0 = 0; q0 < L; q0 += C::KT) {
     __syncthreads();
-    load_rows<D, 64 * NW>(sQ, base + (size_t)q0 * rs, rs, C::KT, tid);
-    load_rows<D, 64 * NW>(sDO, dout + ((size_t)b * L + q0) * D, D, C::KT, tid);
+    load_rows<D, 64 * NW>(sQ, base + (size_t)q0 * rs, rs, C::KT, L - q0, tid);
+    load_rows<D, 64 * NW>(sDO, dout + ((size_t)b * L + q0) * D, D, C::KT, L - q0, tid);
     for (int e = tid; e < C::KT; e += 64 * NW) {
-      sL[e] = lse2[(size_t)b * L + q0 + e];
-      sDl[e] = delta[(size_t)b * L + q0 + e];
+      // queries past a ragged end: log-sum-exp = +huge => probability exactly 0 below
+      const bool ok = q0 + e < L;
+      sL[e] = ok ? lse2[(size_t)b * L + q0 + e] : 1e30f;
+      sDl[e] = ok ? delta[(size_t)b * L + q0 + e] : 0.f;
     }
     __syncthreads();
 #pragma unroll
@@ -337,6 +348,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkdv_kernel(const bf16* __re
     }
   }
   const int ki = kb0 + wave * 32 + (lane & 31);
+  if (ki >= L) return;
   bf16* orow = dqkv + ((size_t)b * L + ki) * rs;
 #pragma unroll
   for (int d = 0; d < DBL; ++d)
@@ -353,7 +365,6 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkdv_kernel(const bf16* __re
 static int attn_check(const char* who, int b, int l, int c) {
   if (b <= 0 || l <= 0) PTI_FAIL(PTI_EINVAL, "%s: bad dims", who);
   if (c != 64 && c != 128 && c != 256) PTI_FAIL(PTI_EUNSUPPORTED, "%s: head dim %d (supported 64, 128, 256)", who, c);
-  if (l % 64) PTI_FAIL(PTI_EUNSUPPORTED, "%s: token count %d must be a multiple of 64", who, l);
   return 0;
 }
 
@@ -361,7 +372,7 @@ extern "C" int pti_attention_fwd(const void* qkv, void* o, float* lse2, int b, i
   if (!qkv || !o || !lse2) PTI_FAIL(PTI_EINVAL, "attention_fwd: null pointer");
   if (int rc = attn_check("attention_fwd", b, l, c)) return rc;
   const float c_log2 = 1.4426950408889634f / sqrtf((float)c);
-  dim3 grid(l / TB, b), blk(64 * NW);
+  dim3 grid((l + TB - 1) / TB, b), blk(64 * NW);
   hipStream_t st = (hipStream_t)s;
   if (c == 64) hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, blk, 0, st, (const bf16*)qkv, (bf16*)o, lse2, l, c_log2);
   else if (c == 128) hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, blk, 0, st, (const bf16*)qkv, (bf16*)o, lse2, l, c_log2);
@@ -381,7 +392,7 @@ extern "C" int pti_attention_bwd(const void* qkv, const void* o, const void* dou
   if (db > 4096) db = 4096;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)db), dim3(256), 0, st, (const bf16*)o, (const bf16*)dout, delta, rows, c);
   PTI_CHECK_LAUNCH("attention_delta");
-  dim3 grid(l / TB, b), blk(64 * NW);
+  dim3 grid((l + TB - 1) / TB, b), blk(64 * NW);
   const bf16* Q = (const bf16*)qkv; const bf16* DO = (const bf16*)dout; bf16* DQ = (bf16*)dqkv;
   if (c == 64) {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, grid, blk, 0, st, Q, DO, lse2, delta, DQ, l, c_log2, scale);
@@ -391,7 +402,7 @@ extern "C" int pti_attention_bwd(const void* qkv, const void* o, const void* dou
     hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128, 1>), grid, blk, 0, st, Q, DO, lse2, delta, DQ, l, c_log2, scale);
   } else {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<256>, grid, blk, 0, st, Q, DO, lse2, delta, DQ, l, c_log2, scale);
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<256, 2>), dim3(l / TB, b, 2), blk, 0, st, Q, DO, lse2, delta, DQ, l, c_log2, scale);
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<256, 2>), dim3((l + TB - 1) / TB, b, 2), blk, 0, st, Q, DO, lse2, delta, DQ, l, c_log2, scale);
   }
   PTI_CHECK_LAUNCH("attention_bwd");
   return PTI_OK;

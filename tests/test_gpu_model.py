@@ -179,3 +179,34 @@ def test_api_surface(dev):
         model.autoencoder.encode(x)          # CPU tensor: no fallback
     with pytest.raises(ValueError):
         model.autoencoder.encode(torch.zeros(1, 1, 60, 60, device=dev))
+
+
+def test_ragged_batch_and_non_square_image(dev):
+    """Batch 3, 72x104 pixels (not a multiple of any 16- or 32-pixel tile; latent 9x13): forward parity and one
+    training step's gradients, so that every kernel's edge-tile masking is exercised inside the whole model."""
+    from oracle.autoencoderkl import CONFIG_A, synthetic_images
+    from oracle.losses import train_step_losses
+    from pti_ldm_vae_amd.models import compute_kl_loss
+    torch.set_num_threads(8)
+    oracle, model = _build(CONFIG_A, dev)
+    x = synthetic_images(3, 1, 104, seed=7)[:, :, :72, :].contiguous()
+    eps = torch.randn(3, 4, 9, 13, generator=torch.Generator().manual_seed(8))
+    loss_o, rec_l_o, kl_o, _ = train_step_losses(oracle, x, eps)
+    loss_o.backward()
+    with torch.no_grad():
+        rec_o, mu_o, _ = oracle(x, eps)
+    xd, epsd = x.to(dev), eps.to(dev)
+    rec, mu, sig = _fwd_hip(model, xd, epsd)
+    mse = ((rec.detach().cpu() - rec_o) ** 2).mean().item()
+    print(f"[A@72x104 b3] recon MSE {mse:.3e} mu relL2 {_rel(mu.detach().cpu(), mu_o):.3e}")
+    assert rec.shape == x.shape and mse <= 1e-4 and _rel(mu.detach().cpu(), mu_o) <= 2e-2
+    loss = torch.nn.functional.l1_loss(rec, xd) + 1e-3 * compute_kl_loss(mu, sig)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert loss.item() == pytest.approx(loss_o.item(), rel=1e-2)
+    go = {n: p.grad for n, p in oracle.named_parameters()}
+    fg = torch.cat([p.grad.detach().cpu().flatten() for _, p in model.autoencoder.named_parameters()])
+    fo = torch.cat([go[n].flatten() for n, _ in model.autoencoder.named_parameters()])
+    cos = torch.nn.functional.cosine_similarity(fg, fo, dim=0).item()
+    print(f"[A@72x104 b3] grad cosine {cos:.5f} norm ratio {(fg.norm() / fo.norm()).item():.4f}")
+    assert torch.isfinite(fg).all() and cos >= 0.995
