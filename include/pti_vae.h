@@ -65,7 +65,9 @@ typedef struct pti_conv_desc {
   /* activated inputs, attention tensors and all gradients are bf16.  res_f16 also describes the  */
   /* GroupNorm input `gx` of pti_conv2d_mfma_gnbwd.                                               */
   int32_t in_f16, res_f16, out_f16;
-  int32_t reserved_;
+  /* pti_conv2d_mfma only: y is [n][ho/2][wo/2][cout] = the 2x2 SUM pool of the conv output (the data      */
+  /* gradient of nn.Upsample(nearest, 2x) + conv, fused: the full-resolution gradient is never written).   */
+  int32_t pool2x2_out;
 } pti_conv_desc;
 
 int pti_abi_version(void);

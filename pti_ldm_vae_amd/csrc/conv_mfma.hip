@@ -83,6 +83,7 @@ struct ConvArgs {
   bf16* act_out;
   // 16-bit storage format of x / residual (or the GN input of the fused backward) / y: 0 = bf16, 1 = fp16
   int in_f16, res_f16, out_f16;
+  int pool2;   // v2 kernel: store the 2x2-sum-pooled output tile [N][Ho/2][Wo/2][Cout] (data gradient of nearest-2x up-sampling)
 };
 
 template <int KS, int S, int CK, int COUT_TILE>
@@ -775,6 +776,34 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
   }
   __syncthreads();
   // (C) LDS tile -> global, 16 bytes per lane, consecutive lanes on consecutive addresses
+  if (a.pool2) {
+    // data gradient of  conv(nearest-2x(x)): the gradient w.r.t. x is the 2x2 sum of the gradient w.r.t. the
+    // up-sampled map -- summed here (fp32) from the LDS tile instead of writing the full-resolution map and
+    // pooling it in a second pass.  Tile origins and sizes are even, so every 2x2 cell lies inside one tile.
+    constexpr int PITERS = (C::EITERS + 3) / 4;
+#pragma unroll
+    for (int it = 0; it < PITERS; ++it) {
+      const int idx = tid + it * 256;
+      const int c8 = idx % C::ENC, pp = idx / C::ENC;
+      const int py = pp / 8, px = pp % 8;
+      const int oy = (oy0 >> 1) + py, ox = (ox0 >> 1) + px;
+      if (pp < C::MPX / 4 && oy < (a.Ho >> 1) && ox < (a.Wo >> 1)) {
+        const unsigned char* src = etile + ((2 * py) * 16 + 2 * px) * C::EPITCH + c8 * 16;
+        float s_[8], f_[8];
+        unpack8f(*(const u32x4*)src, s_, a.out_f16);
+        unpack8f(*(const u32x4*)(src + C::EPITCH), f_, a.out_f16);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s_[q] += f_[q];
+        unpack8f(*(const u32x4*)(src + 16 * C::EPITCH), f_, a.out_f16);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s_[q] += f_[q];
+        unpack8f(*(const u32x4*)(src + 17 * C::EPITCH), f_, a.out_f16);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s_[q] += f_[q];
+        *(u32x4*)(a.y + ((size_t)(n * (a.Ho >> 1) + oy) * (a.Wo >> 1) + ox) * a.Cout + ct * CT + c8 * 8) = pack8f(s_, a.out_f16);
+      }
+    }
+  } else
 #pragma unroll
   for (int it = 0; it < C::EITERS; ++it) {
     const int p = epp0 + it * EPSTEP;
@@ -1026,6 +1055,9 @@ static int conv2d_mfma_impl(const void* x, const void* w_packed, const float* bi
   a.g_stats = a.g_gamma = a.g_beta = nullptr; a.g_sums = nullptr;
   a.act_out = (bf16*)act_out;
   a.in_f16 = d->in_f16; a.res_f16 = d->res_f16; a.out_f16 = d->out_f16;
+  a.pool2 = d->pool2x2_out;
+  if (a.pool2 && (d->mode == PTI_CONV_S2PAD || d->accum_stats || gf || (d->ho & 1) || (d->wo & 1)))
+    PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: pool2x2_out needs a stride-1 gather, even output size, no fused statistics");
   a.eps = d->eps;
   a.inv_cnt = d->prologue != PTI_PRO_NONE ? 1.0f / ((float)(d->cin / d->groups) * (float)d->h * (float)d->w) : 0.f;
   if (gf) {

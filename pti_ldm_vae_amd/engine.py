@@ -100,12 +100,12 @@ class _MfmaConv:
             out = _empty((n, 2 * ho, 2 * wo, self.cin), dy)
             ops.conv_mfma(dy, self.wpt, None, out, cout=self.cin, ksize=3, mode=PTI_CONV_ZINS, residual=residual)
             return out
+        if self.mode == PTI_CONV_UP2:   # gradient w.r.t. the pre-up-sampling map: 2x2 sum pool fused into the epilogue
+            pooled = _empty((n, ho // 2, wo // 2, self.cin), dy)
+            ops.conv_mfma(dy, self.wpt, None, pooled, cout=self.cin, ksize=self.ksize, mode=PTI_CONV_S1, pool2=True)
+            return pooled
         out = _empty((n, ho, wo, self.cin), dy)
         ops.conv_mfma(dy, self.wpt, None, out, cout=self.cin, ksize=self.ksize, mode=PTI_CONV_S1, residual=residual)
-        if self.mode == PTI_CONV_UP2:
-            pooled = _empty((n, ho // 2, wo // 2, self.cin), dy)
-            ops.pool2x2_sum(out, pooled)
-            return pooled
         return out
 
     def dgrad_gn(self, dy, x, norm, *, silu, dres, eng):

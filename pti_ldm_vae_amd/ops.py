@@ -85,8 +85,10 @@ def gn_stats(x, groups, stats=None):
 
 
 def conv_mfma(x, w_packed, bias, y, *, cout, ksize=3, mode=PTI_CONV_S1, prologue=PTI_PRO_NONE, in_stats=None,
-              gamma=None, beta=None, groups=0, eps=1e-6, residual=None, out_stats=None, out_groups=0, act_out=None):
-    """``act_out`` (optional, bf16, x's shape): also write prologue(x) for the weight-gradient pass to reuse."""
+              gamma=None, beta=None, groups=0, eps=1e-6, residual=None, out_stats=None, out_groups=0, act_out=None,
+              pool2=False):
+    """``act_out`` (optional, bf16, x's shape): also write prologue(x) for the weight-gradient pass to reuse.
+    ``pool2``: y is [n, ho/2, wo/2, cout], the 2x2 sum pool of the conv output (fused nearest-2x up-sampling backward)."""
     _chk(x, ACT16, "x", 4)
     _chk(y, ACT16, "y", 4)
     n, h, w, cin = x.shape
@@ -95,8 +97,9 @@ def conv_mfma(x, w_packed, bias, y, *, cout, ksize=3, mode=PTI_CONV_S1, prologue
         if act_out.shape != x.shape:
             raise ValueError("conv_mfma: act_out shape")
     ho, wo = conv_out_hw(h, w, mode)
-    if tuple(y.shape) != (n, ho, wo, cout):
-        raise ValueError(f"conv_mfma: y shape {tuple(y.shape)} != {(n, ho, wo, cout)}")
+    yshape = (n, ho // 2, wo // 2, cout) if pool2 else (n, ho, wo, cout)
+    if tuple(y.shape) != yshape:
+        raise ValueError(f"conv_mfma: y shape {tuple(y.shape)} != {yshape}")
     if w_packed.numel() != cout * cin * ksize * ksize or w_packed.dtype != BF16:
         raise ValueError("conv_mfma: packed weight size/dtype mismatch")
     if bias is not None:
@@ -110,7 +113,7 @@ def conv_mfma(x, w_packed, bias, y, *, cout, ksize=3, mode=PTI_CONV_S1, prologue
                 raise ValueError(f"conv_mfma: {nm} size")
     if residual is not None:
         _chk(residual, ACT16, "residual", 4)
-        if residual.shape != y.shape:
+        if residual.shape != y.shape or pool2:
             raise ValueError("conv_mfma: residual shape")
     if out_stats is not None:
         _chk(out_stats, F32, "out_stats")
@@ -119,7 +122,8 @@ def conv_mfma(x, w_packed, bias, y, *, cout, ksize=3, mode=PTI_CONV_S1, prologue
     d = ConvDesc(n=n, h=h, w=w, cin=cin, ho=ho, wo=wo, cout=cout, ksize=ksize, mode=mode, prologue=prologue,
                  groups=groups, add_residual=int(residual is not None), accum_stats=int(out_stats is not None),
                  out_groups=out_groups, eps=eps, in_f16=int(x.dtype == F16),
-                 res_f16=int(residual is not None and residual.dtype == F16), out_f16=int(y.dtype == F16))
+                 res_f16=int(residual is not None and residual.dtype == F16), out_f16=int(y.dtype == F16),
+                 pool2x2_out=int(pool2))
     prof = KERNEL_PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -138,7 +142,7 @@ def conv_mfma(x, w_packed, bias, y, *, cout, ksize=3, mode=PTI_CONV_S1, prologue
         # algorithmic work; the zero-insert data gradient only has 1/4 useful taps per output pixel
         flops = 2.0 * n * ho * wo * cout * cin * ksize * ksize * (0.25 if mode == PTI_CONV_ZINS else 1.0)
         # algorithmic bytes: read the input once (bf16), write the output once (+ residual read)
-        nbytes = 2.0 * (x.numel() * (2 if act_out is not None else 1) + y.numel() * (2 if residual is not None else 1))
+        nbytes = 2.0 * (x.numel() * (2 if act_out is not None else 1) + y.numel() * (2 if residual is not None else 1))   # (pooled y counted as stored)
         prof.append((name, flops, nbytes, e0, e1))
     return y
 

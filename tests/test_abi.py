@@ -52,8 +52,8 @@ def test_validation_errors_before_launch():
     d = _lib.ConvDesc(n=1, h=8, w=8, cin=32, ho=8, wo=8, cout=32, ksize=3)
     rc = h.pti_conv2d_mfma(None, None, None, None, None, None, None, None, None, C.byref(d), None)
     assert rc == -1 and b"null" in h.pti_last_error_string()
-    rc = h.pti_attention_fwd(C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), 1, 96, 128, None)
-    assert rc == -2 and b"multiple of 64" in h.pti_last_error_string()
+    rc = h.pti_attention_fwd(C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), 1, 96, 96, None)
+    assert rc == -2 and b"head dim" in h.pti_last_error_string()
     with pytest.raises(_lib.PtiError):
         _lib.check(rc, "attention")
 

@@ -250,3 +250,19 @@ def test_wgrad_direct(dev, kind, n, cw, cn, h, w, pro):
     torch.cuda.synchronize()
     _report(f"wgrad_direct[{kind}] dW", dw, wt.grad, max_frac=2e-3 if pro else 1e-4, l2=1e-3 if pro else 2e-5)
     _report(f"wgrad_direct[{kind}] db", db, b.grad, max_frac=1e-4, l2=2e-5)
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 32, 32, 16, 16), (1, 64, 64, 12, 20), (2, 128, 128, 8, 16), (1, 128, 64, 10, 6)])
+def test_conv_mfma_pooled_output(dev, n, cin, cout, h, w):
+    """pool2x2_out: y = 2x2 sum pool of the stride-1 conv output (the nearest-2x up-sampling data gradient)."""
+    from pti_ldm_vae_amd import ops
+    torch.manual_seed(3)
+    x = _r(torch.randn(n, cin, h, w))
+    wt = _r(torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5)
+    full = _r(F.conv2d(x, wt, None, padding=1))        # the unfused path rounds the full-resolution map to bf16 first
+    ref = 4.0 * F.avg_pool2d(full, 2)
+    y = torch.full((n, h // 2, w // 2, cout), float("nan"), dtype=torch.bfloat16, device=dev)
+    ops.conv_mfma(_nhwc(x).to(dev, torch.bfloat16), ops.pack_conv_weight(wt.to(dev), 3, ops.PTI_CONV_S1), None, y, cout=cout,
+                  pool2=True)
+    torch.cuda.synchronize()
+    _report(f"conv_mfma pooled[{cin}->{cout} {h}x{w}]", y.float().cpu().permute(0, 3, 1, 2), ref)
