@@ -72,9 +72,23 @@ def cpu_baseline(cfg_def, size, batch, steps):
         if i > 0:
             times.append(time.perf_counter() - t0)
     dt = sum(times) / len(times)
+    # the reference's own thread setting (torch.set_num_threads(4), train_vae.py:94), one timed step
+    torch.set_num_threads(min(4, cores))
+    t4 = []
+    for i in range(2):
+        eps = torch.randn(batch, cfg_def["latent_channels"], lat, lat)
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        loss, *_ = train_step_losses(model, x, eps)
+        loss.backward()
+        opt.step()
+        t4.append(time.perf_counter() - t0)
+    torch.set_num_threads(cores)
     return {"value": round(batch / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "value_at_reference_threads": round(batch / t4[-1], 4), "reference_threads": min(4, cores),
             "sample": f"oracle fp32 train step (fwd+L1+KL+bwd+Adam), config A {size}x{size}, batch {batch}, "
-                      f"1 warm-up + {steps} timed steps, torch threads={cores}"}
+                      f"1 warm-up + {steps} timed steps, torch threads={cores}; plus 1 warm-up + 1 timed step at the "
+                      f"reference's torch.set_num_threads(4)"}
 
 
 def main():
