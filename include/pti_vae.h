@@ -216,6 +216,15 @@ int pti_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
 int pti_cast_nchw_f32_to_nhwc_bf16(const float* x, void* y, int n, int c, int hw, pti_stream_t s);
 int pti_cast_nhwc_bf16_to_nchw_f32(const void* x, float* y, int n, int c, int hw, pti_stream_t s);
 
+/* ---- input pipeline ---------------------------------------------------- */
+/* Batch form of the reference's per-sample transform chain Resize(patch_size) [MONAI default mode "area" =     *
+ * adaptive average pooling] -> LocalNormalizeByMask -> float32 (data/dataloaders.py:319-329,                    *
+ * data/transforms.py:8-32).  src: the raw fp32 images of the batch concatenated; offsets[b], hw[b] = {H, W}:    *
+ * where image b starts and its size (device arrays); out: [b][1][hp][wp] fp32; stats: device scratch of 3*b     *
+ * doubles (zeroed here).                                                                                        */
+int pti_preprocess_batch(const float* src, const int64_t* offsets, const int32_t* hw, int b, int hp, int wp,
+                         float* out, double* stats, pti_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

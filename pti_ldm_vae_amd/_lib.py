@@ -66,6 +66,7 @@ SIGNATURES = {
     "pti_latent_head_bwd": (_I, [_P] * 18 + [_I, _I, _I, _P]),
     "pti_vae_loss": (_I, [_P, _P, _I64, _P, _P, _I64, _I, _P, _P, _P, _P, _I, _I, _F, _P]),
     "pti_adam_step": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I, _F, _P]),
+    "pti_preprocess_batch": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "pti_cast_nchw_f32_to_nhwc_bf16": (_I, [_P, _P, _I, _I, _I, _P]),
     "pti_cast_nhwc_bf16_to_nchw_f32": (_I, [_P, _P, _I, _I, _I, _P]),
 }

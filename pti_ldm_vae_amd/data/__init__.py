@@ -1,0 +1,6 @@
+"""Input pipeline of the VAE training path: TIFF files -> device batches."""
+from .loader import DeviceImageLoader, create_vae_dataloaders, list_tif_paths, shard_indices, split_paths
+from .tiff import read_tiff, write_tiff
+
+__all__ = ["DeviceImageLoader", "create_vae_dataloaders", "list_tif_paths", "shard_indices", "split_paths", "read_tiff",
+           "write_tiff"]

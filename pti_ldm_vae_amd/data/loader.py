@@ -1,0 +1,180 @@
+"""TIFF directory -> device-resident training batches.
+
+Mirrors what ``create_vae_dataloaders`` of the reference sets up (``src/pti_ldm_vae/data/dataloaders.py:370-593``):
+the path listing (``:15-47``), the seeded shuffle + ``train_split`` cut (``:469-513``), the per-sample transform
+chain ``LoadImage -> EnsureChannelFirst -> Resize(patch_size) -> LocalNormalizeByMask -> float32`` (``:319-329``) and
+``DistributedSampler`` sharding (``:545-550``) -- but the transform chain runs on the GPU:
+
+  host threads decode TIFFs into one pinned staging buffer  ->  ONE H2D copy per batch on a copy stream  ->
+  ``pti_preprocess_batch`` (area resize + masked z-score, two launches) on that stream  ->  an event the training
+  stream waits on.  Two batches are in flight (double buffering), so decode + copy + preprocessing of batch k+1
+  overlap the optimiser step of batch k.
+
+Not mirrored (stated, not silently dropped): attribute files of the AR-VAE branch, ``cache_rate`` (the whole decoded
+set is small enough to keep in page cache), MONAI meta-tensors.  Axis order: the TIFF is taken row-major as (H, W);
+which reader MONAI's ``LoadImage`` picks for ``.tif`` (and whether it transposes) cannot be checked offline -- with
+the square patches of every reference config this only mirrors the image, it does not change the statistics.
+"""
+from __future__ import annotations
+
+import random
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from .tiff import read_tiff
+
+
+def list_tif_paths(data_base_dir: str, data_source: str = "edente") -> list[str]:
+    """``_list_tif_paths`` (dataloaders.py:15-47): ``*.tif`` directly in the directory, else in its ``edente`` /
+    ``dente`` sub-folders (``both`` = edente then dente), sorted."""
+    base = Path(data_base_dir)
+    direct = sorted(base.glob("*.tif"))
+    if direct:
+        return [str(p) for p in direct]
+    if data_source == "edente":
+        paths = sorted((base / "edente").glob("*.tif"))
+    elif data_source == "dente":
+        paths = sorted((base / "dente").glob("*.tif"))
+    elif data_source == "both":
+        paths = sorted((base / "edente").glob("*.tif")) + sorted((base / "dente").glob("*.tif"))
+    else:
+        raise ValueError(f"data_source must be 'edente', 'dente', or 'both', got '{data_source}'")
+    if not paths:
+        raise FileNotFoundError(f"no .tif image found in {data_base_dir}/{data_source}")
+    return [str(p) for p in paths]
+
+
+def split_paths(paths: list[str], train_split: float = 0.9, seed: int | None = 42, subset_size: int | None = None,
+                val_paths: list[str] | None = None) -> tuple[list[str], list[str]]:
+    """Seeded shuffle and cut (dataloaders.py:469-513): ``random.seed(seed); random.shuffle(copy)``, first
+    ``int(train_split * n)`` paths train, the rest validate; an external validation list keeps every path for
+    training.  ``subset_size`` truncates the sorted list first, as the reference does before shuffling."""
+    paths = list(paths)
+    if subset_size is not None:
+        paths = paths[:subset_size]
+    if seed is not None:
+        random.seed(seed)
+        random.shuffle(paths)
+    if val_paths is not None:
+        return paths, list(val_paths)
+    cut = int(train_split * len(paths))
+    return paths[:cut], paths[cut:]
+
+
+def shard_indices(n: int, rank: int, world: int, shuffle: bool, seed: int, epoch: int) -> list[int]:
+    """Indices ``torch.utils.data.DistributedSampler(num_replicas=world, rank, shuffle, seed)`` yields after
+    ``set_epoch(epoch)`` with ``drop_last=False``: a ``seed + epoch`` permutation (or ``range``), padded by wrapping
+    around to a multiple of ``world``, every ``world``-th element starting at ``rank``."""
+    if shuffle:
+        g = torch.Generator()
+        g.manual_seed(seed + epoch)
+        idx = torch.randperm(n, generator=g).tolist()
+    else:
+        idx = list(range(n))
+    total = -(-n // world) * world
+    pad = total - len(idx)
+    if pad:
+        idx += (idx * (pad // len(idx) + 1))[:pad]
+    return idx[rank:total:world]
+
+
+class DeviceImageLoader:
+    """Iterable over device batches ``[b, 1, Hp, Wp]`` fp32 of the preprocessed images at ``paths``.
+
+    ``set_epoch(e)`` selects the permutation (as ``DistributedSampler.set_epoch``); iteration order, padding and the
+    last (short) batch follow ``DataLoader(batch_size, sampler=DistributedSampler(...))``.  Each yielded tensor is
+    safe to use on the current stream; it stays valid until two further batches have been requested."""
+
+    def __init__(self, paths: list[str], batch_size: int, patch_size: tuple[int, int], device, *, rank: int = 0,
+                 world_size: int = 1, shuffle: bool = True, seed: int = 42, num_workers: int = 4):
+        from .. import ops
+        self._ops = ops
+        self.paths, self.batch, self.patch = list(paths), int(batch_size), (int(patch_size[0]), int(patch_size[1]))
+        self.dev = torch.device(device)
+        self.rank, self.world, self.shuffle, self.seed, self.epoch = rank, world_size, shuffle, seed, 0
+        self.pool = ThreadPoolExecutor(max_workers=max(1, num_workers))
+        self.copy_stream = torch.cuda.Stream(device=self.dev)
+        self._slots = [dict(pinned=None, dev=None, out=None, stats=None, event=None) for _ in range(3)]
+
+    def set_epoch(self, epoch: int) -> None:
+        self.epoch = int(epoch)
+
+    def __len__(self) -> int:
+        n = len(shard_indices(len(self.paths), self.rank, self.world, False, 0, 0))
+        return -(-n // self.batch)
+
+    @staticmethod
+    def _decode(path: str) -> np.ndarray:
+        img = read_tiff(path)
+        return np.ascontiguousarray(img, dtype=np.float32)
+
+    def _stage(self, slot: dict, idx: list[int]):
+        imgs = list(self.pool.map(self._decode, [self.paths[i] for i in idx]))
+        sizes = [im.size for im in imgs]
+        total = sum(sizes)
+        if slot["pinned"] is None or slot["pinned"].numel() < total:
+            cap = max(total, int(1.25 * total))
+            slot["pinned"] = torch.empty(cap, dtype=torch.float32).pin_memory()
+            slot["dev"] = torch.empty(cap, dtype=torch.float32, device=self.dev)
+        host = slot["pinned"].numpy()
+        offs, o = [], 0
+        for im, s in zip(imgs, sizes):
+            host[o:o + s] = im.reshape(-1)
+            offs.append(o)
+            o += s
+        b = len(imgs)
+        desc = torch.tensor(offs, dtype=torch.int64).pin_memory()
+        hw = torch.tensor([[im.shape[0], im.shape[1]] for im in imgs], dtype=torch.int32).pin_memory()
+        with torch.cuda.stream(self.copy_stream):
+            # allocated in the copy stream's pool; the consumer stream is recorded on it when it is yielded
+            out = torch.empty(b, 1, *self.patch, dtype=torch.float32, device=self.dev)
+            slot["dev"][:total].copy_(slot["pinned"][:total], non_blocking=True)
+            d_off = desc.to(self.dev, non_blocking=True)
+            d_hw = hw.to(self.dev, non_blocking=True)
+            self._ops.preprocess_batch(slot["dev"], d_off, d_hw, out)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+        slot["event"], slot["out"], slot["keep"] = ev, out, (desc, hw, d_off, d_hw)
+        return slot
+
+    def __iter__(self):
+        idx = shard_indices(len(self.paths), self.rank, self.world, self.shuffle, self.seed, self.epoch)
+        batches = [idx[i:i + self.batch] for i in range(0, len(idx), self.batch)]
+        if not batches:
+            return
+        pending = self._stage(self._slots[0], batches[0])
+        for k in range(len(batches)):
+            cur = pending
+            if k + 1 < len(batches):
+                # the pinned buffer of the slot being refilled was last read by a copy issued two batches ago
+                nxt = self._slots[(k + 1) % 3]
+                if nxt["event"] is not None:
+                    nxt["event"].synchronize()
+                pending = self._stage(nxt, batches[k + 1])
+            torch.cuda.current_stream(self.dev).wait_event(cur["event"])
+            cur["out"].record_stream(torch.cuda.current_stream(self.dev))
+            yield cur["out"]
+
+
+def create_vae_dataloaders(data_base_dir: str, batch_size: int, patch_size: tuple[int, int], rank: int = 0,
+                           data_source: str = "edente", train_split: float = 0.9, num_workers: int = 4,
+                           seed: int | None = 42, subset_size: int | None = None, val_dir: str | None = None,
+                           distributed: bool = False, world_size: int = 1, device="cuda", **_ignored):
+    """Same signature prefix and return shape as the reference's ``create_vae_dataloaders``:
+    ``(train_loader, val_loader, train_paths, val_paths)`` with loaders that yield device batches."""
+    if not 0 < train_split < 1:
+        raise ValueError(f"train_split must be in (0, 1), got {train_split}")
+    paths = list_tif_paths(data_base_dir, data_source)
+    val_list = list_tif_paths(val_dir, data_source) if val_dir is not None else None
+    train_paths, val_paths = split_paths(paths, train_split, seed, subset_size, val_list)
+    world = world_size if distributed else 1
+    r = rank if distributed else 0
+    s = seed if seed is not None else 0
+    train = DeviceImageLoader(train_paths, batch_size, patch_size, device, rank=r, world_size=world, shuffle=True, seed=s,
+                              num_workers=num_workers)
+    val = DeviceImageLoader(val_paths, batch_size, patch_size, device, rank=r, world_size=world, shuffle=False, seed=s,
+                            num_workers=num_workers)
+    return train, val, train_paths, val_paths

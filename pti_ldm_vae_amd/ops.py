@@ -483,3 +483,20 @@ class BatchedPacker:
     def run(self):
         L.check(L.lib().pti_conv_pack_weights_batched(_ptr(self.table), _ptr(self.first), self.n, self.total_blocks,
                                                       _stream()), "pti_conv_pack_weights_batched")
+
+
+def preprocess_batch(src, offsets, hw, out, stats=None):
+    """Resize(area) + LocalNormalizeByMask of a batch of raw fp32 images (see include/pti_vae.h).
+    src: flat fp32 device tensor; offsets int64 [B]; hw int32 [B,2]; out fp32 [B,1,Hp,Wp]."""
+    _chk(src, F32, "src")
+    _chk(out, F32, "out", 4)
+    b, _, hp, wp = out.shape
+    if offsets.dtype != torch.int64 or hw.dtype != torch.int32 or offsets.numel() != b or hw.numel() != 2 * b:
+        raise ValueError("preprocess_batch: offsets must be int64 [B], hw int32 [B,2]")
+    if not (offsets.is_cuda and hw.is_cuda and offsets.is_contiguous() and hw.is_contiguous()):
+        raise ValueError("preprocess_batch: descriptor tables must be contiguous device tensors")
+    if stats is None:
+        stats = torch.empty(3 * b, dtype=torch.float64, device=out.device)
+    L.check(L.lib().pti_preprocess_batch(_ptr(src), _ptr(offsets), _ptr(hw), b, hp, wp, _ptr(out), _ptr(stats), _stream()),
+            "pti_preprocess_batch")
+    return out

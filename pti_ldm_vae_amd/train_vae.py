@@ -115,6 +115,22 @@ class SyntheticShards:
             yield torch.stack([self._image(j) for j in idx[i:i + self.batch]])
 
 
+class TiffShards:
+    """The same ``batches(epoch, train)`` interface over a directory of .tif images (pti_ldm_vae_amd.data)."""
+
+    def __init__(self, base_dir, batch, patch, rank, world, seed, device, *, data_source, train_split, subset_size, val_dir,
+                 num_workers):
+        from .data import create_vae_dataloaders
+        self.train, self.val, self.train_paths, self.val_paths = create_vae_dataloaders(
+            base_dir, batch, patch, rank=rank, data_source=data_source, train_split=train_split, num_workers=num_workers,
+            seed=seed, subset_size=subset_size, val_dir=val_dir, distributed=world > 1, world_size=world, device=device)
+
+    def batches(self, epoch, train=True):
+        loader = self.train if train else self.val
+        loader.set_epoch(epoch if train else 0)
+        yield from loader
+
+
 def save_checkpoints(args, model, opt, epoch, val_loss, best_val_loss, best_epoch_saved, total_step, rank):
     """train_vae.py:675-769: always ``autoencoder_last.pt``; on improvement replace the best files."""
     if rank != 0:
@@ -181,9 +197,6 @@ def main(argv=None):
                              "  1. Change 'run_dir' in your config file, or\n  2. Set 'resume_ckpt: true' to continue training")
         Path(args.model_dir).mkdir(parents=True, exist_ok=True)
         (run_dir / "splits").mkdir(parents=True, exist_ok=True)
-    if not args.synthetic:
-        raise SystemExit("train_vae: the TIFF data pipeline is out of scope this round (SURVEY.md §8f N1); "
-                         "run with --synthetic N")
     torch.manual_seed(args.seed)                    # set_determinism(args.seed)
     model = VAEModel.from_config(args.autoencoder_def).to(device)
     if rank == 0:
@@ -193,14 +206,24 @@ def main(argv=None):
                          kl_weight=tr["kl_weight"], rank_eps_offset=rank)
     start_epoch, best_val, total_step, best_epoch_saved = load_checkpoint(args, model, trainer.opt, device)
     model.autoencoder.mark_weights_dirty()
-    n = args.subset_size or args.synthetic
-    data = SyntheticShards(n, args.autoencoder_def["in_channels"], tuple(tr["patch_size"]), tr["batch_size"], rank, world,
-                           args.seed, device, args.train_split)
+    if args.synthetic:
+        n = args.subset_size or args.synthetic
+        data = SyntheticShards(n, args.autoencoder_def["in_channels"], tuple(tr["patch_size"]), tr["batch_size"], rank, world,
+                               args.seed, device, args.train_split)
+        train_files = [f"synthetic:{i}" for i in range(data.n_train)]
+        val_files = [f"synthetic:{i}" for i in range(data.n_train, data.n_train + data.n_val)]
+    else:
+        # TIFF directory -> device batches (create_vae_dataloaders, train_vae.py:832-850 of the reference)
+        if args.autoencoder_def["in_channels"] != 1:
+            raise SystemExit("train_vae: the TIFF pipeline produces single-channel images (in_channels must be 1)")
+        data = TiffShards(args.data_base_dir, tr["batch_size"], tuple(tr["patch_size"]), rank, world, args.seed, device,
+                          data_source=getattr(args, "data_source", "edente"), train_split=args.train_split,
+                          subset_size=args.subset_size, val_dir=getattr(args, "val_dir", None), num_workers=args.num_workers)
+        train_files, val_files = data.train_paths, data.val_paths
     if rank == 0:
         with open(Path(args.run_dir) / "splits" / "vae_split.json", "w", encoding="utf-8") as f:
             json.dump({"seed": args.seed, "train_split": args.train_split, "subset_size": args.subset_size,
-                       "val_dir": args.val_dir, "train_files": [f"synthetic:{i}" for i in range(data.n_train)],
-                       "val_files": [f"synthetic:{i}" for i in range(data.n_train, data.n_train + data.n_val)]}, f, indent=2)
+                       "val_dir": args.val_dir, "train_files": train_files, "val_files": val_files}, f, indent=2)
     log = open(Path(args.run_dir) / "metrics.jsonl", "a") if rank == 0 else None
     kl_w, max_epochs, val_interval = tr["kl_weight"], tr["max_epochs"], tr["val_interval"]
     for epoch in range(start_epoch, max_epochs):
