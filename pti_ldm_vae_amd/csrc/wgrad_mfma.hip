@@ -551,7 +551,9 @@ extern "C" int pti_conv_wgrad_mfma_partials(const void* x, const void* dy, const
   const int kk = d->ksize * d->ksize;
   a.slab_stride = (long long)kk * d->cout * d->cin + d->cout;
   const long long smax = workspace_bytes / (a.slab_stride * 4);
-  int S = (v3 ? 1280 : 512) / tiles_cc;      // v3: three waves per workgroup, ~5 workgroups per CU
+  // v3: three waves per workgroup; 768 workgroups = 3 per CU measured best (512 .. 2048 within +-8 %: fewer
+  // workgroups mean fewer 37-KB partial slabs to write and reduce, more mean more loads in flight)
+  int S = (v3 ? 768 : 512) / tiles_cc;
   if (S > a.ntiles / 4) S = a.ntiles / 4;
   if (S > (v3 ? 512 : 256)) S = v3 ? 512 : 256;
   if (S < 1) S = 1;
