@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgArgs a) {
 }
 
 // =============================================================================================
-// v3 (3x3, stride-1 gathers): 32co x 32ci block per workgroup, THREE waves, wave = kernel row kh.
+// v3 (3x3, stride-1 gathers): 32co x 32ci block per workgroup, THREE waves, wave = kernel column kw.
 // Measured on v1 (144 accumulator VGPRs per wave => 2 waves/SIMD, one 20 KB tile in flight per workgroup):
 // the loop is bound by HBM latency x bytes in flight (Little's law), ~2-3 TB/s.  Splitting the 9 taps over
 // three waves leaves 48 accumulator VGPRs per wave => ~5 workgroups per CU, i.e. ~100 KB of loads in flight
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(192) void wgrad_mfma3_kernel(WgArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS_BYTES];
   unsigned char* lA = smem;
   unsigned char* lD = smem + C::A_BYTES;
-  const int tid = threadIdx.x, lane = tid & 63, kh = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, kw = tid >> 6;   // wave = kernel COLUMN (see the main loop)
   // XCD-aware block order: consecutive workgroup ids go round-robin over the 8 XCDs (one L2 each), so the
   // (co, ci) blocks that stream the SAME pixel tiles (same split) are placed on the same XCD, back to back:
   // id = 8 * (tiles_cc * (split / 8) + cc) + split % 8.  Host guarantees S % 8 == 0 or S < 8 (then id = S * cc + split).
@@ -411,36 +411,44 @@ __global__ __launch_bounds__(192) void wgrad_mfma3_kernel(WgArgs a) {
     __syncthreads();
     const int nxt = tile + a.S;
     if (nxt < a.ntiles) n_next = issue(nxt);
+    // Wave kw walks the TH+2 halo rows once: the x fragment of halo row r (column offset kw) meets the dy
+    // fragments of output rows r, r-1, r-2 for kernel rows kh = 0, 1, 2.  Each dy fragment is read once and kept for
+    // three rows, each x fragment is read once: 4 transposing LDS reads per 3 MFMAs (wave = kernel row needed 8:
+    // at ~120 KB of LDS traffic per tile the kernel was LDS-bound, not MFMA-bound).
+    bf16x8 dfr[C::TH];
 #pragma unroll
-    for (int row = 0; row < C::TH; ++row) {
-      const unsigned char* dptr = lD + fbase + row * TW * C::PP;
-      const v4s d0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(dptr));
-      const v4s d1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(dptr + 4 * C::PP));
-      v8s td = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
-      const bf16x8 dfrag = __builtin_bit_cast(bf16x8, td);
-      const unsigned char* arow = lA + fbase + (row + kh) * C::HW * C::PP;
+    for (int r = 0; r < C::TH + 2; ++r) {
+      if (r < C::TH) {
+        const unsigned char* dptr = lD + fbase + r * TW * C::PP;
+        const v4s d0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(dptr));
+        const v4s d1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(dptr + 4 * C::PP));
+        v8s td = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+        dfr[r] = __builtin_bit_cast(bf16x8, td);
+      }
+      const unsigned char* aptr = lA + fbase + (r * C::HW + kw) * C::PP;
+      const v4s a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(aptr));
+      const v4s a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(aptr + 4 * C::PP));
+      v8s ta = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+      const bf16x8 afr = __builtin_bit_cast(bf16x8, ta);
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const unsigned char* aptr = arow + kw * C::PP;
-        const v4s a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(aptr));
-        const v4s a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(aptr + 4 * C::PP));
-        v8s ta = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-        acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfrag, __builtin_bit_cast(bf16x8, ta), acc[kw], 0, 0, 0);
+      for (int kh = 0; kh < 3; ++kh) {
+        const int o = r - kh;          // output row whose halo row o + kh is r
+        if (o >= 0 && o < C::TH) acc[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfr[o], afr, acc[kh], 0, 0, 0);
       }
     }
     __syncthreads();
   }
 
-  // ---- epilogue: wave kh owns taps kh*3 .. kh*3+2 of the slab [tap][co][ci] ----
+  // ---- epilogue: wave kw owns taps kw, 3 + kw, 6 + kw of the slab [tap][co][ci] ----
   float* slab = a.slab + (size_t)split * a.slab_stride;
   const int ci = cit * 32 + (lane & 31);
   const int hsel = lane >> 5;
 #pragma unroll
-  for (int kw = 0; kw < 3; ++kw)
+  for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = cot * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
-      slab[((size_t)(kh * 3 + kw) * a.Cout + co) * a.Cin + ci] = acc[kw][r];
+      slab[((size_t)(kh * 3 + kw) * a.Cout + co) * a.Cin + ci] = acc[kh][r];
     }
   if (cit == 0) {   // bias partials: threads with equal lc hold the same 8 channels
     float* red = reinterpret_cast<float*>(smem);
