@@ -57,6 +57,35 @@ __device__ __forceinline__ bf16x8 acc_to_frag(const f32x16& x, int s) {
 }
 
 // cooperative copy of `rows` token rows (D bf16 each) from global (row stride gstride elements) to LDS
+// Streamed tiles go global -> registers -> LDS in two steps: all 16-byte pieces of a tile are ISSUED together
+// (issue_rows) right after the previous tile was stored, so they fly under the MFMAs of the current tile, and are
+// written to LDS (store_rows) at the top of the next iteration.  (A plain load/store loop waited for each piece in
+// turn: 16 dependent L2 round trips per 64-token tile, ~6x the MFMA time at one wave per SIMD.)
+template <int D, int NT, int ROWS>
+struct RowRegs {
+  static constexpr int N = ROWS * (D / 8) / NT;
+  u32x4 r[N];
+};
+template <int D, int NT, int ROWS>
+__device__ __forceinline__ void issue_rows(RowRegs<D, NT, ROWS>& rr, const bf16* src, size_t gstride, int valid, int tid) {
+  constexpr int NC = D / 8;
+#pragma unroll
+  for (int i = 0; i < RowRegs<D, NT, ROWS>::N; ++i) {
+    const int e = tid + i * NT, r = e / NC, c = e % NC;
+    rr.r[i] = u32x4{0u, 0u, 0u, 0u};
+    if (r < valid) rr.r[i] = *(const u32x4*)(src + (size_t)r * gstride + c * 8);
+  }
+}
+template <int D, int NT, int ROWS>
+__device__ __forceinline__ void store_rows(unsigned char* tile, const RowRegs<D, NT, ROWS>& rr, int tid) {
+  constexpr int NC = D / 8;
+#pragma unroll
+  for (int i = 0; i < RowRegs<D, NT, ROWS>::N; ++i) {
+    const int e = tid + i * NT, r = e / NC, c = e % NC;
+    *(u32x4*)(tile + r * ACfg<D>::P + c * 16) = rr.r[i];
+  }
+}
+
 // (rows at or beyond `valid` -- past the end of a token count that is not a multiple of the tile -- are zero-filled)
 template <int D, int NT>
 __device__ __forceinline__ void load_rows(unsigned char* tile, const bf16* src, size_t gstride, int rows, int valid, int tid) {
@@ -94,11 +123,18 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const bf16* __restric
     for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
   float m = -1e30f, lsum = 0.f;
 
+  RowRegs<D, 64 * NW, C::KT> rk, rv;
+  issue_rows(rk, base + D, rs, L, tid);
+  issue_rows(rv, base + 2 * D, rs, L, tid);
   for (int k0 = 0; k0 < L; k0 += C::KT) {
     __syncthreads();
-    load_rows<D, 64 * NW>(sK, base + (size_t)k0 * rs + D, rs, C::KT, L - k0, tid);
-    load_rows<D, 64 * NW>(sV, base + (size_t)k0 * rs + 2 * D, rs, C::KT, L - k0, tid);
+    store_rows<D, 64 * NW, C::KT>(sK, rk, tid);
+    store_rows<D, 64 * NW, C::KT>(sV, rv, tid);
     __syncthreads();
+    if (k0 + C::KT < L) {
+      issue_rows(rk, base + (size_t)(k0 + C::KT) * rs + D, rs, L - k0 - C::KT, tid);
+      issue_rows(rv, base + (size_t)(k0 + C::KT) * rs + 2 * D, rs, L - k0 - C::KT, tid);
+    }
     f32x16 sacc[C::NB];
 #pragma unroll
     for (int kb = 0; kb < C::NB; ++kb) {
@@ -221,11 +257,18 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const bf16* __rest
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
 
+  RowRegs<D, 64 * NW, C::KT> rk, rv;
+  issue_rows(rk, base + D, rs, L, tid);
+  issue_rows(rv, base + 2 * D, rs, L, tid);
   for (int k0 = 0; k0 < L; k0 += C::KT) {
     __syncthreads();
-    load_rows<D, 64 * NW>(sK, base + (size_t)k0 * rs + D, rs, C::KT, L - k0, tid);
-    load_rows<D, 64 * NW>(sV, base + (size_t)k0 * rs + 2 * D, rs, C::KT, L - k0, tid);
+    store_rows<D, 64 * NW, C::KT>(sK, rk, tid);
+    store_rows<D, 64 * NW, C::KT>(sV, rv, tid);
     __syncthreads();
+    if (k0 + C::KT < L) {
+      issue_rows(rk, base + (size_t)(k0 + C::KT) * rs + D, rs, L - k0 - C::KT, tid);
+      issue_rows(rv, base + (size_t)(k0 + C::KT) * rs + 2 * D, rs, L - k0 - C::KT, tid);
+    }
 #pragma unroll
     for (int kb = 0; kb < C::NB; ++kb) {
       f32x16 sa, dp;
@@ -305,10 +348,13 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkdv_kernel(const bf16* __re
     for (int r = 0; r < 16; ++r) dk[d][r] = dv[d][r] = 0.f;
   const int h = lane >> 5;
 
+  RowRegs<D, 64 * NW, C::KT> rq, rdo;
+  issue_rows(rq, base, rs, L, tid);
+  issue_rows(rdo, dout + (size_t)b * L * D, D, L, tid);
   for (int q0 = 0; q0 < L; q0 += C::KT) {
     __syncthreads();
-    load_rows<D, 64 * NW>(sQ, base + (size_t)q0 * rs, rs, C::KT, L - q0, tid);
-    load_rows<D, 64 * NW>(sDO, dout + ((size_t)b * L + q0) * D, D, C::KT, L - q0, tid);
+    store_rows<D, 64 * NW, C::KT>(sQ, rq, tid);
+    store_rows<D, 64 * NW, C::KT>(sDO, rdo, tid);
     for (int e = tid; e < C::KT; e += 64 * NW) {
       // queries past a ragged end: log-sum-exp = +huge => probability exactly 0 below
       const bool ok = q0 + e < L;
@@ -316,6 +362,10 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkdv_kernel(const bf16* __re
       sDl[e] = ok ? delta[(size_t)b * L + q0 + e] : 0.f;
     }
     __syncthreads();
+    if (q0 + C::KT < L) {
+      issue_rows(rq, base + (size_t)(q0 + C::KT) * rs, rs, L - q0 - C::KT, tid);
+      issue_rows(rdo, dout + ((size_t)b * L + q0 + C::KT) * D, D, L - q0 - C::KT, tid);
+    }
 #pragma unroll
     for (int qb = 0; qb < C::NB; ++qb) {
       f32x16 sa, dp;
