@@ -510,19 +510,6 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
     };
     if constexpr (!(SAVE && PXF == 2)) wload(wa, 0);   // (side-output variant at the 128-VGPR cap: after staging)
 
-    float sc[8], sh[8];
-    if (a.prologue != PTI_PRO_NONE) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int ch = chunk * CK + lc * 8 + j;
-        const int g = ch / cpg;
-        const float sum = a.in_stats[(n * a.groups + g) * 2], sq = a.in_stats[(n * a.groups + g) * 2 + 1];
-        const float mean = sum * a.inv_cnt;
-        const float rstd = rsqrtf(fmaxf(sq * a.inv_cnt - mean * mean, 0.f) + a.eps);
-        sc[j] = rstd * a.gamma[ch];
-        sh[j] = a.beta[ch] - mean * sc[j];
-      }
-    }
     u32x4 raw[C::HITERS];
     bool ok[C::HITERS];
 #pragma unroll
@@ -540,6 +527,21 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
       ok[it] = v;
       raw[it] = u32x4{0u, 0u, 0u, 0u};
       if (v) raw[it] = *(const u32x4*)(a.x + ((size_t)(n * a.H + iy) * a.W + ix) * a.Cin + chunk * CK + lc * 8);
+    }
+    // GroupNorm scale / shift of this thread's 8 channels: fetched AFTER the halo loads were issued, so that the
+    // statistics / gamma / beta round trips (L2) overlap the halo's HBM round trip instead of preceding it
+    float sc[8], sh[8];
+    if (a.prologue != PTI_PRO_NONE) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int ch = chunk * CK + lc * 8 + j;
+        const int g = ch / cpg;
+        const float sum = a.in_stats[(n * a.groups + g) * 2], sq = a.in_stats[(n * a.groups + g) * 2 + 1];
+        const float mean = sum * a.inv_cnt;
+        const float rstd = rsqrtf(fmaxf(sq * a.inv_cnt - mean * mean, 0.f) + a.eps);
+        sc[j] = rstd * a.gamma[ch];
+        sh[j] = a.beta[ch] - mean * sc[j];
+      }
     }
     if (chunk > 0) __syncthreads();  // every wave is done reading the previous chunk's halo
 #pragma unroll
