@@ -209,6 +209,10 @@ def main():
         dist.barrier()
 
     if rank == 0:
+        # algorithmic GFLOP per image and training step at 256x256 (BASELINE.md §3 / SURVEY.md §8d)
+        gflop_img = {(32, 64, 128, 128): TRAIN_GFLOP_PER_IMG_A, (64, 128, 256, 256): 730.6}.get(tuple(cfg_def["channels"]))
+        if args.size != 256:
+            gflop_img = gflop_img * (args.size / 256.0) ** 2 if gflop_img else None   # convs scale with pixels (attention ~L^2 ignored)
         imgs = args.batch * world * args.steps
         value = imgs / dt
         per_gpu = value / world
@@ -216,12 +220,12 @@ def main():
             "metric": "vae_train_images_per_sec_256x256_bf16", "value": round(value, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"config/vae_dente_no_adv.json {args.size}x{args.size}x{cfg_def['in_channels']} "
+            "config": {"workload": f"config/{os.path.basename(args.config)} {args.size}x{args.size}x{cfg_def['in_channels']} "
                                    f"batch {args.batch}/GPU: fwd + L1 + 1e-3*KL + bwd + all-reduce + Adam "
                                    "(perceptual/adversarial terms omitted: unavailable offline / inactive before epoch 6)",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss, 5)},
-            "model_tflops_per_gpu": round(per_gpu * TRAIN_GFLOP_PER_IMG_A / 1e3, 1),
-            "frac_of_mfma_peak_end_to_end": round(per_gpu * TRAIN_GFLOP_PER_IMG_A / 1e3 / PEAK_BF16_TFLOPS, 4),
+            "model_tflops_per_gpu": round(per_gpu * gflop_img / 1e3, 1) if gflop_img else None,
+            "frac_of_mfma_peak_end_to_end": round(per_gpu * gflop_img / 1e3 / PEAK_BF16_TFLOPS, 4) if gflop_img else None,
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
