@@ -210,7 +210,7 @@ def main():
 
     if rank == 0:
         # algorithmic GFLOP per image and training step at 256x256 (BASELINE.md §3 / SURVEY.md §8d)
-        gflop_img = {(32, 64, 128, 128): TRAIN_GFLOP_PER_IMG_A, (64, 128, 256, 256): 730.6}.get(tuple(cfg_def["channels"]))
+        gflop_img = {(32, 64, 128, 128): TRAIN_GFLOP_PER_IMG_A, (64, 128, 256): 730.6}.get(tuple(cfg_def["channels"]))
         if args.size != 256:
             gflop_img = gflop_img * (args.size / 256.0) ** 2 if gflop_img else None   # convs scale with pixels (attention ~L^2 ignored)
         imgs = args.batch * world * args.steps
