@@ -360,7 +360,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
 //    launch is only 2 rounds of 2 workgroups/CU and every workgroup is in the same phase at the same time.
 //  * 1-row x 32-pixel fragments shared across the 3 kernel rows (-40 % LDS reads): no gain (LDS ~21 % busy).
 //  * PXF = 2 at 3-4 workgroups/CU, weight ring 3/6/9 deep: all within +-3 %.  A start delay for every other
-//    workgroup: slower.  Next: persistent workgroups with cross-tile halo prefetch.
+//    workgroup: slower.  64-channel chunks with the next chunk's halo prefetched into registers under the current
+//    chunk's MFMAs (246-253 VGPRs): no gain.  Next: persistent workgroups with cross-tile halo prefetch.
 // =============================================================================================
 __host__ __device__ constexpr int pick_ck2(int cin, int ct) {
   const int ck = cin % 128 == 0 ? 128 : (cin % 64 == 0 ? 64 : 32);
