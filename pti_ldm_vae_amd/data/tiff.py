@@ -1,12 +1,14 @@
 """Minimal baseline-TIFF reader / writer for the single-channel scientific images the reference trains on
 (float32 .tif files read by MONAI ``LoadImage`` -> tifffile; ``vae_scripts/README.md:259``).  tifffile is not
 installed in this environment, so the subset that those files use is implemented here with the struct module:
-classic TIFF (magic 42), little or big endian, uncompressed strips, one sample per pixel, 8/16/32-bit unsigned or
-signed integers and 32/64-bit floats.  Tiled, compressed, multi-sample or BigTIFF files raise ``ValueError`` naming
-the unsupported feature."""
+classic TIFF (magic 42), little or big endian, strips that are uncompressed or zlib/deflate-compressed (codes 8 and
+32946, no predictor), one sample per pixel, 8/16/32-bit unsigned or signed integers and 32/64-bit floats.  Tiled,
+LZW/JPEG-compressed, predictor-coded, multi-sample or BigTIFF files raise ``ValueError`` naming the unsupported
+feature."""
 from __future__ import annotations
 
 import struct
+import zlib
 
 import numpy as np
 
@@ -58,8 +60,11 @@ def read_tiff(path: str) -> np.ndarray:
         if t not in tags:
             raise ValueError(f"{path}: missing TIFF tag {t}" + (" (tiled TIFFs are not supported)" if 322 in tags else ""))
     width, height = tags[256][0], tags[257][0]
-    if tags.get(259, (1,))[0] != 1:
-        raise ValueError(f"{path}: compressed TIFF (compression={tags[259][0]}) is not supported")
+    comp = tags.get(259, (1,))[0]
+    if comp not in (1, 8, 32946):
+        raise ValueError(f"{path}: compressed TIFF (compression={comp}) is not supported (only none and deflate)")
+    if comp != 1 and tags.get(317, (1,))[0] != 1:
+        raise ValueError(f"{path}: deflate with predictor {tags[317][0]} is not supported")
     if tags.get(277, (1,))[0] != 1:
         raise ValueError(f"{path}: {tags[277][0]} samples per pixel; only single-channel images are supported")
     bits = tags.get(258, (1,))[0]
@@ -76,9 +81,17 @@ def read_tiff(path: str) -> np.ndarray:
     for si, off in enumerate(offsets):
         rows = min(rows_per_strip, height - row)
         nbytes = rows * width * dtype.itemsize
-        if counts is not None and counts[si] < nbytes:
-            raise ValueError(f"{path}: strip {si} is shorter than its rows")
-        out[row:row + rows] = np.frombuffer(buf, dtype=dtype, count=rows * width, offset=off).reshape(rows, width)
+        if comp == 1:
+            if counts is not None and counts[si] < nbytes:
+                raise ValueError(f"{path}: strip {si} is shorter than its rows")
+            out[row:row + rows] = np.frombuffer(buf, dtype=dtype, count=rows * width, offset=off).reshape(rows, width)
+        else:
+            if counts is None:
+                raise ValueError(f"{path}: compressed strips need StripByteCounts")
+            raw = zlib.decompress(buf[off:off + counts[si]])
+            if len(raw) < nbytes:
+                raise ValueError(f"{path}: strip {si} inflates to {len(raw)} bytes, {nbytes} expected")
+            out[row:row + rows] = np.frombuffer(raw, dtype=dtype, count=rows * width).reshape(rows, width)
         row += rows
         if row >= height:
             break
@@ -87,8 +100,9 @@ def read_tiff(path: str) -> np.ndarray:
     return out
 
 
-def write_tiff(path: str, image: np.ndarray, rows_per_strip: int | None = None, big_endian: bool = False) -> None:
-    """Write a 2-D array as an uncompressed single-strip (or multi-strip) classic TIFF."""
+def write_tiff(path: str, image: np.ndarray, rows_per_strip: int | None = None, big_endian: bool = False,
+               deflate: bool = False) -> None:
+    """Write a 2-D array as a single-strip (or multi-strip) classic TIFF, uncompressed or deflate-compressed."""
     a = np.ascontiguousarray(image)
     if a.ndim != 2:
         raise ValueError("write_tiff: 2-D arrays only")
@@ -100,8 +114,11 @@ def write_tiff(path: str, image: np.ndarray, rows_per_strip: int | None = None, 
     h, w = a.shape
     rps = rows_per_strip or h
     nstrips = (h + rps - 1) // rps
-    data = a.tobytes()
-    strip_bytes = [min(rps, h - i * rps) * w * a.itemsize for i in range(nstrips)]
+    strips = [a[i * rps:(i + 1) * rps].tobytes() for i in range(nstrips)]
+    if deflate:
+        strips = [zlib.compress(b_, 6) for b_ in strips]
+    data = b"".join(strips)
+    strip_bytes = [len(b_) for b_ in strips]
     data_off = 8
     strip_offs = [data_off + sum(strip_bytes[:i]) for i in range(nstrips)]
     extra_off = data_off + len(data)
@@ -118,7 +135,7 @@ def write_tiff(path: str, image: np.ndarray, rows_per_strip: int | None = None, 
             extra += raw
         return struct.pack(bo + "HHI", tag, typ, len(vals)) + field
 
-    entries = [entry(256, 4, [w]), entry(257, 4, [h]), entry(258, 3, [a.itemsize * 8]), entry(259, 3, [1]),
+    entries = [entry(256, 4, [w]), entry(257, 4, [h]), entry(258, 3, [a.itemsize * 8]), entry(259, 3, [8 if deflate else 1]),
                entry(262, 3, [1]), entry(273, 4, strip_offs), entry(277, 3, [1]), entry(278, 4, [rps]),
                entry(279, 4, strip_bytes), entry(339, 3, [kind])]
     ifd_off = extra_off + len(extra)

@@ -21,6 +21,16 @@ def test_tiff_roundtrip(tmp_path, dtype, big, rps):
     assert b.shape == a.shape and b.dtype == np.dtype(dtype) and np.array_equal(a, b)
 
 
+def test_tiff_deflate_roundtrip(tmp_path):
+    rng = np.random.default_rng(1)
+    a = rng.standard_normal((50, 31)).astype(np.float32)
+    a[a < 0.3] = 0.0
+    p = str(tmp_path / "z.tif")
+    write_tiff(p, a, rows_per_strip=8, deflate=True)
+    assert os.path.getsize(p) < a.nbytes          # really compressed
+    assert np.array_equal(read_tiff(p), a)
+
+
 def test_tiff_known_bytes(tmp_path):
     """A hand-assembled little-endian 2x2 uint8 TIFF (not produced by write_tiff)."""
     import struct
@@ -47,7 +57,7 @@ def test_tiff_rejects_unsupported(tmp_path):
     assert i > 0
     raw[i + 8] = 5
     open(q, "wb").write(bytes(raw))
-    with pytest.raises(ValueError, match="compress"):
+    with pytest.raises(ValueError, match="compress"):      # LZW: named, not mis-decoded
         read_tiff(q)
 
 
