@@ -587,8 +587,8 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
           const int vy = vy0 + hy, vx = vx0 + hx;
           if (vy < a.H && vx < a.W) {
             const int key = (hx >> C::KEY_SHIFT) & (C::NC - 1);
-            *(u32x4*)(a.act_out + ((size_t)(n * a.H + vy) * a.W + vx) * a.Cin + chunk * CK + c8 * 8) =
-                *(const u32x4*)(halo + (hy * C::HW + hx) * C::PIXB + ((c8 ^ key) << 4));
+            __builtin_nontemporal_store(*(const u32x4*)(halo + (hy * C::HW + hx) * C::PIXB + ((c8 ^ key) << 4)),
+                                        (u32x4*)(a.act_out + ((size_t)(n * a.H + vy) * a.W + vx) * a.Cin + chunk * CK + c8 * 8));
           }
         }
       }
@@ -803,7 +803,8 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
         unpack8f(*(const u32x4*)(src + 17 * C::EPITCH), f_, a.out_f16);
 #pragma unroll
         for (int q = 0; q < 8; ++q) s_[q] += f_[q];
-        *(u32x4*)(a.y + ((size_t)(n * (a.Ho >> 1) + oy) * (a.Wo >> 1) + ox) * a.Cout + ct * CT + c8 * 8) = pack8f(s_, a.out_f16);
+        __builtin_nontemporal_store(pack8f(s_, a.out_f16),
+                                    (u32x4*)(a.y + ((size_t)(n * (a.Ho >> 1) + oy) * (a.Wo >> 1) + ox) * a.Cout + ct * CT + c8 * 8));
       }
     }
   } else
@@ -812,8 +813,9 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
     const int p = epp0 + it * EPSTEP;
     const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
     if (oy < a.Ho && ox < a.Wo)
-      *(u32x4*)(a.y + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.Cout + ct * CT + epc * 8) =
-          *(const u32x4*)(etile + p * C::EPITCH + epc * 16);
+      // non-temporal: the output is not re-read by this launch; keeping it out of L2's way measured -1.1 % per step
+      __builtin_nontemporal_store(*(const u32x4*)(etile + p * C::EPITCH + epc * 16),
+                                  (u32x4*)(a.y + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.Cout + ct * CT + epc * 8));
   }
   if (a.gn_mode) {
     if (tid < 2 * CT)
