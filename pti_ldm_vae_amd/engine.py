@@ -125,9 +125,25 @@ class _MfmaConv:
     def wgrad(self, x, dy, *, pro=PTI_PRO_NONE, norm=None, eng=None):
         dw, db = self.grads()
         g, b = (norm.weight.data, norm.bias.data) if norm is not None else (None, None)
-        ops.conv_wgrad_mfma(x.t, dy, dw, db, ksize=self.ksize, mode=self.mode, prologue=pro,
-                            in_stats=x.stats if pro else None, gamma=g, beta=b, groups=eng.G, eps=eng.eps,
-                            accumulate=True, workspace=eng.workspace)
+        ws = eng.wgrad_stream
+        if ws is None:
+            ops.conv_wgrad_mfma(x.t, dy, dw, db, ksize=self.ksize, mode=self.mode, prologue=pro,
+                                in_stats=x.stats if pro else None, gamma=g, beta=b, groups=eng.G, eps=eng.eps,
+                                accumulate=True, workspace=eng.workspace)
+            return
+        # weight gradients are off the data-gradient chain: they run on a side stream, behind an event that marks
+        # "x and dy exist", and are joined before their gradients are used (Engine.join_wgrad)
+        cur = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        ws.wait_event(ev)
+        x.t.record_stream(ws)
+        dy.record_stream(ws)
+        with torch.cuda.stream(ws):
+            ops.conv_wgrad_mfma(x.t, dy, dw, db, ksize=self.ksize, mode=self.mode, prologue=pro,
+                                in_stats=x.stats if pro else None, gamma=g, beta=b, groups=eng.G, eps=eng.eps,
+                                accumulate=True, workspace=eng.workspace_side)
+        eng._wgrad_pending = True
 
 
 class _Norm:
@@ -302,6 +318,11 @@ class Engine:
         # an 8x finer rounding step (GroupNorm keeps the range far inside fp16's); MFMA operands, saved activated
         # inputs, attention tensors and every gradient are bf16 either way.  PTI_FWD_ACT_DTYPE=bf16 restores bf16.
         self.act_dtype = {"fp16": torch.float16, "bf16": BF16}[os.environ.get("PTI_FWD_ACT_DTYPE", "fp16")]
+        # MFMA weight-gradient launches go to a side stream with its own split-K workspace (PTI_WGRAD_STREAM=0: same
+        # stream): they are off the data-gradient chain, and their ramp-up / drain overlaps it (-3.4 % per step)
+        self.wgrad_stream = torch.cuda.Stream(device=self.dev) if os.environ.get("PTI_WGRAD_STREAM", "1") == "1" else None
+        self.workspace_side = torch.empty_like(self.workspace) if self.wgrad_stream is not None else None
+        self._wgrad_pending = False
         ops.L.lib()  # fail loudly now if the HIP extension is missing
         for c in net.channels:
             if c % 32:
@@ -416,6 +437,14 @@ class Engine:
             self._ready(l.prefix)
         return dout
 
+    def join_wgrad(self):
+        """Make the current stream wait for the side-stream weight gradients issued so far."""
+        if self.wgrad_stream is not None and self._wgrad_pending:
+            ev = torch.cuda.Event()
+            ev.record(self.wgrad_stream)
+            torch.cuda.current_stream().wait_event(ev)
+            self._wgrad_pending = False
+
     def _ready(self, *prefixes):
         """Tell the data-parallel exchange that the gradients of these blocks are final."""
         cb = self.grad_ready_cb
@@ -429,8 +458,21 @@ class Engine:
                     lo = o if lo is None else min(lo, o)
                     hi = o + (n + 3) // 4 * 4 if hi is None else max(hi, o + (n + 3) // 4 * 4)
             rng = self._range_cache[prefixes] = (lo, hi)
-        if rng[0] is not None:
+        if rng[0] is None:
+            return
+        ws = self.wgrad_stream
+        if ws is None:
             cb(*rng)
+            return
+        # the block's gradients come from BOTH streams (weight gradients on the side stream, norm / bias / direct-conv
+        # gradients on the main one): the side stream waits for the main stream up to here and the exchange is
+        # enqueued behind the side stream, so the data-gradient chain on the main stream is never held up
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        ws.wait_event(ev)
+        with torch.cuda.stream(ws):
+            cb(*rng)
+        self._wgrad_pending = True
 
     # ---- encoder --------------------------------------------------------------------------------
     def encode_forward(self, x, save):
@@ -501,6 +543,7 @@ class Engine:
         ops.wgrad_direct(dout, x, gv(ei.prefix + ".weight"), n=n, h=h, w=w, cw=c0, cn=cin, ksize=3, sgn=-1,
                          narrow_layout="nchw", dw_strides=(1, cin * 9, 9), dbias_wide=gv(ei.prefix + ".bias"))
         self._ready("encoder.blocks.0.")
+        self.join_wgrad()
         if not want_dx:
             return None
         dx = torch.empty_like(x)
@@ -560,6 +603,7 @@ class Engine:
         dz = torch.empty_like(z) if want_dz else None
         ops.post_quant_bwd(dzq, z, wp, dz, gv("post_quant_conv.conv.weight"), gv("post_quant_conv.conv.bias"))
         self._ready("post_quant_conv.")
+        self.join_wgrad()
         return dz
 
     # ---- autograd entry points --------------------------------------------------------------------
