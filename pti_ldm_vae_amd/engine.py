@@ -437,6 +437,21 @@ class Engine:
             self._ready(l.prefix)
         return dout
 
+    def _wgrad_direct(self, wide, narrow, *args, **kw):
+        """ops.wgrad_direct on the weight-gradient side stream (same protocol as _MfmaConv.wgrad)."""
+        ws = self.wgrad_stream
+        if ws is None:
+            ops.wgrad_direct(wide, narrow, *args, **kw)
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        ws.wait_event(ev)
+        wide.record_stream(ws)
+        narrow.record_stream(ws)
+        with torch.cuda.stream(ws):
+            ops.wgrad_direct(wide, narrow, *args, workspace=self.workspace_side, **kw)
+        self._wgrad_pending = True
+
     def join_wgrad(self):
         """Make the current stream wait for the side-stream weight gradients issued so far."""
         if self.wgrad_stream is not None and self._wgrad_pending:
@@ -527,7 +542,7 @@ class Engine:
         # encoder conv_out (norm + 3x3, C -> L): weight grads, then data grad through the norm
         eo, nm = self.enc_out, self.enc_out.norm
         C = act.t.shape[3]
-        ops.wgrad_direct(act.t, dh.view(n, hl, wl, L), gv(eo.prefix + ".weight"), n=n, h=hl, w=wl, cw=C, cn=L, ksize=3,
+        self._wgrad_direct(act.t, dh.view(n, hl, wl, L), gv(eo.prefix + ".weight"), n=n, h=hl, w=wl, cw=C, cn=L, ksize=3,
                          sgn=1, narrow_layout="nhwc", dw_strides=(1, 9, C * 9), dbias_narrow=gv(eo.prefix + ".bias"),
                          prologue=PTI_PRO_GN, in_stats=act.stats, gamma=nm.weight.data, beta=nm.bias.data, groups=self.G,
                          eps=self.eps)
@@ -540,7 +555,7 @@ class Engine:
         ei = self.enc_in
         _, cin, h, w = x.shape
         c0 = dout.shape[3]
-        ops.wgrad_direct(dout, x, gv(ei.prefix + ".weight"), n=n, h=h, w=w, cw=c0, cn=cin, ksize=3, sgn=-1,
+        self._wgrad_direct(dout, x, gv(ei.prefix + ".weight"), n=n, h=h, w=w, cw=c0, cn=cin, ksize=3, sgn=-1,
                          narrow_layout="nchw", dw_strides=(1, cin * 9, 9), dbias_wide=gv(ei.prefix + ".bias"))
         self._ready("encoder.blocks.0.")
         self.join_wgrad()
@@ -583,7 +598,7 @@ class Engine:
         do, nm = self.dec_out, self.dec_out.norm
         h, w, C = act.t.shape[1], act.t.shape[2], act.t.shape[3]
         co = do.cout
-        ops.wgrad_direct(act.t, drecon, gv(do.prefix + ".weight"), n=n, h=h, w=w, cw=C, cn=co, ksize=3, sgn=1,
+        self._wgrad_direct(act.t, drecon, gv(do.prefix + ".weight"), n=n, h=h, w=w, cw=C, cn=co, ksize=3, sgn=1,
                          narrow_layout="nchw", dw_strides=(1, 9, C * 9), dbias_narrow=gv(do.prefix + ".bias"),
                          prologue=PTI_PRO_GN, in_stats=act.stats, gamma=nm.weight.data, beta=nm.bias.data, groups=self.G,
                          eps=self.eps)
@@ -593,7 +608,7 @@ class Engine:
         self._ready(do.prefix[:-4], nm.prefix + ".")
         dout = self._walk_bwd(self.dec_layers, dout, saved)
         di = self.dec_in
-        ops.wgrad_direct(dout, zq.view(n, hl, wl, L), gv(di.prefix + ".weight"), n=n, h=hl, w=wl, cw=di.cout, cn=L,
+        self._wgrad_direct(dout, zq.view(n, hl, wl, L), gv(di.prefix + ".weight"), n=n, h=hl, w=wl, cw=di.cout, cn=L,
                          ksize=3, sgn=-1, narrow_layout="nhwc", dw_strides=(1, L * 9, 9),
                          dbias_wide=gv(di.prefix + ".bias"))
         self._ready("decoder.blocks.0.")
