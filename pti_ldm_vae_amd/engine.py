@@ -589,7 +589,9 @@ class Engine:
         ctx = (z, zq, a0, saved, act) if save else None
         return recon, ctx
 
-    def decode_backward(self, ctx, drecon, want_dz=True):
+    def decode_backward(self, ctx, drecon, want_dz=True, join=True):
+        """``join=False``: leave the side-stream weight gradients running (the caller goes on to
+        ``encode_backward``, whose final join covers them: one in-order side stream)."""
         z, zq, a0, saved, act = ctx
         net, gv = self.net, self.net.grad_view
         n, L, hl, wl = z.shape
@@ -618,7 +620,8 @@ class Engine:
         dz = torch.empty_like(z) if want_dz else None
         ops.post_quant_bwd(dzq, z, wp, dz, gv("post_quant_conv.conv.weight"), gv("post_quant_conv.conv.bias"))
         self._ready("post_quant_conv.")
-        self.join_wgrad()
+        if join:
+            self.join_wgrad()
         return dz
 
     # ---- autograd entry points --------------------------------------------------------------------

@@ -59,7 +59,7 @@ class VAETrainer:
             d_recon, d_mu, d_third = torch.empty_like(recon), torch.empty_like(mu), torch.empty_like(third)
             ops.vae_loss(recon, images.contiguous().float(), mu, third, out2, d_recon, d_mu, d_third, l2=self.l2,
                          third_mode=self.third_mode, kl_weight=self.kl_weight)
-            dz = eng.decode_backward(c_dec, d_recon, want_dz=True)
+            dz = eng.decode_backward(c_dec, d_recon, want_dz=True, join=False)   # encode_backward joins the side stream
             # z = mu + eps*sigma ; third = sigma (or 2 log sigma)
             d_sigma = d_third if net.third_output == "sigma" else d_third * (2.0 / sigma)
             d_mu = d_mu + dz
