@@ -212,3 +212,28 @@ def test_ragged_batch_and_non_square_image(dev):
     cos = torch.nn.functional.cosine_similarity(fg, fo, dim=0).item()
     print(f"[A@72x104 b3] grad cosine {cos:.5f} norm ratio {(fg.norm() / fo.norm()).item():.4f}")
     assert torch.isfinite(fg).all() and cos >= 0.995
+
+
+def test_full_size_batch_independence_and_finite(dev):
+    """BASELINE.json's full size (batch 32, 256x256): the oracle would take minutes, so the check is a size-independent
+    property of the path -- GroupNorm is per sample and attention per image, hence every sample's outputs must not
+    depend on what else is in the batch (up to the float-atomic summation order of its own statistics)."""
+    from oracle.autoencoderkl import CONFIG_A, synthetic_images
+    from pti_ldm_vae_amd.models import VAEModel
+    torch.manual_seed(0)
+    model = VAEModel.from_config(CONFIG_A).to(dev).eval()
+    x = synthetic_images(32, 1, 256, seed=11).to(dev)
+    eps = torch.randn(32, 4, 32, 32, generator=torch.Generator().manual_seed(12)).to(dev)
+    with torch.no_grad():
+        rec, mu, sig = _fwd_hip(model, x, eps)
+        idx = [3, 17, 30]
+        rec_s, mu_s, sig_s = _fwd_hip(model, x[idx].contiguous(), eps[idx].contiguous())
+    assert torch.isfinite(rec).all() and torch.isfinite(mu).all() and (sig > 0).all()
+    assert rec.shape == (32, 1, 256, 256) and mu.shape == (32, 4, 32, 32)
+    for name, full, sub in (("recon", rec[idx], rec_s), ("mu", mu[idx], mu_s), ("sigma", sig[idx], sig_s)):
+        rel = _rel(sub, full)
+        print(f"[A@256 b32 vs b3] {name} relL2 {rel:.2e}")
+        assert rel <= 2e-3, (name, rel)
+    # and an empty batch is refused before any launch
+    with pytest.raises((ValueError, RuntimeError)):
+        model.autoencoder.encode(torch.zeros(0, 1, 256, 256, device=dev))
