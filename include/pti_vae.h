@@ -44,6 +44,9 @@ typedef void* pti_stream_t; /* hipStream_t */
 #define PTI_PRO_GN 1      /* x -> GroupNorm affine                nn.GroupNorm                          */
 #define PTI_PRO_GN_SILU 2 /* x -> GroupNorm affine -> SiLU        nn.GroupNorm + F.silu (AEKLResBlock)  */
 
+/* GroupNorm statistics travel as int64 Q47.16 fixed-point {sum, sum of squares} per (sample, group) --           *
+ * `int64_t stats[n][groups][2]`, value = integer / 65536 -- so that accumulating them with atomics is order-       *
+ * independent and every result downstream is bitwise reproducible (see pti_common.h).                              */
 typedef struct pti_conv_desc {
   int32_t n, h, w, cin;   /* real input tensor [n,h,w,cin]                                   */
   int32_t ho, wo, cout;   /* output tensor [n,ho,wo,cout]                                    */
@@ -95,7 +98,7 @@ int pti_conv_pack_weights_batched(const void* table_dev, const int* blk_first_de
 
 /* ---- GroupNorm statistics (nn.GroupNorm's reduction) ---------------------------------- */
 /* stats[n][g] += {sum, sumsq} of x[n, :, channels of g]; stats must be zeroed by the caller. */
-int pti_gn_stats(const void* x_nhwc_16bit, float* stats, int n, int hw, int c, int groups,
+int pti_gn_stats(const void* x_nhwc_16bit, int64_t* stats, int n, int hw, int c, int groups,
                  int x_f16, pti_stream_t s);
 
 /* ---- convolutions ---------------------------------------------------------------------- */
@@ -103,20 +106,20 @@ int pti_gn_stats(const void* x_nhwc_16bit, float* stats, int n, int hw, int c, i
  * y = conv(prologue(x)) + bias [+ residual].  Replaces nn.Conv2d (+ the GroupNorm/SiLU in
  * front of it, + the residual add behind it) inside MONAI AEKLResBlock / AEKLDownsample /
  * Upsample / SABlock linears.  cin, cout multiples of 32.  in_stats: float[n][groups][2].  */
-int pti_conv2d_mfma(const void* x, const void* w_packed, const float* bias, const float* in_stats,
+int pti_conv2d_mfma(const void* x, const void* w_packed, const float* bias, const int64_t* in_stats,
                     const float* gamma, const float* beta, const void* residual, void* y,
-                    float* out_stats, const pti_conv_desc* d, pti_stream_t s);
+                    int64_t* out_stats, const pti_conv_desc* d, pti_stream_t s);
 
 /* Same launch, plus a side output: act_out = prologue(x) as bf16 NHWC [n][h][w][cin] (the tensor autograd
  * would save for nn.Conv2d's weight gradient).  3x3 PTI_CONV_S1 with a GroupNorm(+SiLU) prologue only.  The
  * weight-gradient call then reads act_out with PTI_PRO_NONE instead of re-applying the prologue. */
-int pti_conv2d_mfma_saveact(const void* x, const void* w_packed, const float* bias, const float* in_stats,
+int pti_conv2d_mfma_saveact(const void* x, const void* w_packed, const float* bias, const int64_t* in_stats,
                             const float* gamma, const float* beta, const void* residual, void* y,
-                            float* out_stats, void* act_out, const pti_conv_desc* d, pti_stream_t s);
+                            int64_t* out_stats, void* act_out, const pti_conv_desc* d, pti_stream_t s);
 
 /* Direct (VALU, fp32 math) convolution for the degenerate-channel layers (cin or cout < 32):
  * conv_in, conv_out of Encoder/Decoder.  w: fp32 [k*k][cin][cout]; see pti_conv_desc strides. */
-int pti_conv2d_direct(const void* x, const float* w_tck, const float* bias, const float* in_stats,
+int pti_conv2d_direct(const void* x, const float* w_tck, const float* bias, const int64_t* in_stats,
                       const float* gamma, const float* beta, void* y, const pti_conv_desc* d,
                       pti_stream_t s);
 
@@ -127,7 +130,7 @@ int pti_conv2d_direct(const void* x, const float* w_tck, const float* bias, cons
  * of wide, dbias_narrow[k] += sum of narrow (either may be NULL).  Per-block partials go to `workspace`
  * (plain stores) and are summed in block order by a second launch: deterministic, += into the outputs.  */
 int pti_wgrad_direct(const void* wide, const void* narrow, float* dw, float* dbias_wide,
-                     float* dbias_narrow, const float* in_stats, const float* gamma,
+                     float* dbias_narrow, const int64_t* in_stats, const float* gamma,
                      const float* beta, int n, int h, int w, int cw, int cn, int ksize, int sgn,
                      int prologue, int groups, float eps, int narrow_f32, int wide_f16,
                      const int64_t* narrow_stride, int64_t dw_stride_tap, int64_t dw_stride_cw,
@@ -138,14 +141,14 @@ int64_t pti_conv_wgrad_workspace_bytes(int cout, int cin, int ksize, int splits)
 /* dw[cout][cin][k][k] (fp32, OIHW) and dbias[cout] (=, or += when accumulate) from dy and the
  * SAME x / prologue / mode the forward conv saw (prologue is recomputed in the loader).  Split-K
  * partials go to `workspace` with plain stores and are summed in a fixed order (deterministic). */
-int pti_conv_wgrad_mfma(const void* x, const void* dy, const float* in_stats, const float* gamma,
+int pti_conv_wgrad_mfma(const void* x, const void* dy, const int64_t* in_stats, const float* gamma,
                         const float* beta, float* dw, float* dbias, void* workspace,
                         int64_t workspace_bytes, int accumulate, const pti_conv_desc* d,
                         pti_stream_t s);
 /* The same work as two calls (pti_conv_wgrad_mfma is exactly partials + reduce): the split-K partial launch,
  * which reports the number of slabs it wrote, and the fixed-order slab reduction into dw / dbias.  Lets a
  * caller time or overlap the two launches separately. */
-int pti_conv_wgrad_mfma_partials(const void* x, const void* dy, const float* in_stats,
+int pti_conv_wgrad_mfma_partials(const void* x, const void* dy, const int64_t* in_stats,
                                  const float* gamma, const float* beta, void* workspace,
                                  int64_t workspace_bytes, const pti_conv_desc* d, int* splits_out,
                                  pti_stream_t s);
@@ -155,17 +158,17 @@ int pti_conv_wgrad_reduce(const void* workspace, int splits, float* dw, float* d
 /* ---- GroupNorm(+SiLU) backward, 2x2 sum pool ---------------------------------------------- */
 /* dx = d/dx of act(GroupNorm(x)) given da (+ dres added), dgamma/dbeta += ; sums: zeroed float
  * [n][c][2] scratch; stats as produced by pti_gn_stats on x.  (autograd of nn.GroupNorm+F.silu) */
-int pti_gn_bwd(const void* x, const void* da, const void* dres, void* dx, const float* stats,
+int pti_gn_bwd(const void* x, const void* da, const void* dres, void* dx, const int64_t* stats,
                const float* gamma, const float* beta, float* sums, float* dgamma, float* dbeta,
                int n, int hw, int c, int groups, float eps, int silu, int x_f16, pti_stream_t s);
 /* Fused form used by the engine: the data-gradient conv computes dy = dA * act'(GN(gx)) in its epilogue and
  * accumulates gsums[n][c] = {sum dy, sum dy*xhat} (gx = the GroupNorm input, same shape as the conv output;
  * d->groups / d->eps describe that GroupNorm; d is a plain stride-1 / zero-insert launch, w_packed the
  * transposed+flipped pack).  pti_gn_bwd_apply then finishes dx = rstd*(gamma*dy - c1 - xhat*c2) [+ dres].    */
-int pti_conv2d_mfma_gnbwd(const void* dy_in, const void* w_packed, const void* gx, const float* gstats,
+int pti_conv2d_mfma_gnbwd(const void* dy_in, const void* w_packed, const void* gx, const int64_t* gstats,
                           const float* ggamma, const float* gbeta, void* dy_out, float* gsums,
                           const pti_conv_desc* d, int silu, pti_stream_t s);
-int pti_gn_bwd_apply(const void* x, const void* dy, const void* dres, void* dx, const float* stats,
+int pti_gn_bwd_apply(const void* x, const void* dy, const void* dres, void* dx, const int64_t* stats,
                      const float* gamma, const float* beta, const float* sums, float* dgamma,
                      float* dbeta, int n, int hw, int c, int groups, float eps, int x_f16,
                      pti_stream_t s);

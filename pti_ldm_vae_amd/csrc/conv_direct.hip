@@ -15,7 +15,7 @@ struct DArgs {
   const void* x;
   const float* w;     // [k*k][cin][cout]
   const float* bias;
-  const float* in_stats;
+  const stat_t* in_stats;
   const float* gamma;
   const float* beta;
   void* y;
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void direct_fewcout_kernel(DArgs a, int tiles_
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int ch = lc * 8 + j, g = ch / cpg;
-      const float sum = a.in_stats[(n * a.groups + g) * 2], sq = a.in_stats[(n * a.groups + g) * 2 + 1];
+      const float sum = stat_f(a.in_stats, (n * a.groups + g) * 2), sq = stat_f(a.in_stats, (n * a.groups + g) * 2 + 1);
       const float mean = sum * a.inv_cnt;
       const float rstd = rsqrtf(fmaxf(sq * a.inv_cnt - mean * mean, 0.f) + a.eps);
       sc[j] = rstd * a.gamma[ch];
@@ -248,7 +248,7 @@ struct WGArgs {
   float* dbias_wide;  // optional [CW]: column sums of wide   (FEWCIN layer bias grad)
   float* dbias_narrow;// optional [narrow ch]: sum of narrow   (FEWCOUT layer bias grad)
   float* part;        // workspace: [cn][blocks][80*NC + 1] per-block partial sums (plain stores)
-  const float* in_stats; const float* gamma; const float* beta;
+  const stat_t* in_stats; const float* gamma; const float* beta;
   int N, H, W, CW, KS, sgn;
   int prologue, groups; float eps, inv_cnt;
   int narrow_f32; long long ns[4];
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(WGArgs a) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int ch = lc * 8 + j, g = ch / cpg;
-        const float sum = a.in_stats[(n * a.groups + g) * 2], sq = a.in_stats[(n * a.groups + g) * 2 + 1];
+        const float sum = stat_f(a.in_stats, (n * a.groups + g) * 2), sq = stat_f(a.in_stats, (n * a.groups + g) * 2 + 1);
         const float mean = sum * a.inv_cnt;
         const float rstd = rsqrtf(fmaxf(sq * a.inv_cnt - mean * mean, 0.f) + a.eps);
         sc[j] = rstd * a.gamma[ch];
@@ -446,9 +446,9 @@ __global__ __launch_bounds__(256) void wgrad_direct_finalize_kernel(WGArgs a, in
 
 }  // namespace
 
-static int fill_common(DArgs& a, const void* x, const float* w, const float* bias, const float* st, const float* g,
+static int fill_common(DArgs& a, const void* x, const float* w, const float* bias, const int64_t* st, const float* g,
                        const float* b, void* y, const pti_conv_desc* d) {
-  a.x = x; a.w = w; a.bias = bias; a.in_stats = st; a.gamma = g; a.beta = b; a.y = y;
+  a.x = x; a.w = w; a.bias = bias; a.in_stats = (const stat_t*)st; a.gamma = g; a.beta = b; a.y = y;
   a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout; a.KS = d->ksize;
   a.prologue = d->prologue; a.groups = d->groups; a.eps = d->eps;
   a.inv_cnt = d->prologue ? 1.0f / ((float)(d->cin / d->groups) * (float)d->h * (float)d->w) : 0.f;
@@ -457,7 +457,7 @@ static int fill_common(DArgs& a, const void* x, const float* w, const float* bia
   return 0;
 }
 
-extern "C" int pti_conv2d_direct(const void* x, const float* w, const float* bias, const float* in_stats,
+extern "C" int pti_conv2d_direct(const void* x, const float* w, const float* bias, const int64_t* in_stats,
                                  const float* gamma, const float* beta, void* y, const pti_conv_desc* d,
                                  pti_stream_t s) {
   if (!x || !w || !y || !d) PTI_FAIL(PTI_EINVAL, "conv2d_direct: null pointer");
@@ -501,7 +501,7 @@ extern "C" int pti_conv2d_direct(const void* x, const float* w, const float* bia
 }
 
 extern "C" int pti_wgrad_direct(const void* wide, const void* narrow, float* dw, float* dbias_wide,
-                                float* dbias_narrow, const float* in_stats, const float* gamma, const float* beta,
+                                float* dbias_narrow, const int64_t* in_stats, const float* gamma, const float* beta,
                                 int n, int h, int w, int cw, int cn, int ksize, int sgn, int prologue, int groups,
                                 float eps, int narrow_f32, int wide_f16, const int64_t* narrow_stride, int64_t dw_stride_tap,
                                 int64_t dw_stride_cw, int64_t dw_stride_k, void* workspace, int64_t workspace_bytes,
@@ -512,7 +512,7 @@ extern "C" int pti_wgrad_direct(const void* wide, const void* narrow, float* dw,
   if (prologue && (!in_stats || !gamma || !beta || groups <= 0 || cw % groups)) PTI_FAIL(PTI_EINVAL, "wgrad_direct: prologue args");
   WGArgs a;
   a.wide = (const bf16*)wide; a.narrow = narrow; a.dw = dw; a.dbias_wide = dbias_wide; a.dbias_narrow = dbias_narrow;
-  a.in_stats = in_stats; a.gamma = gamma; a.beta = beta;
+  a.in_stats = (const stat_t*)in_stats; a.gamma = gamma; a.beta = beta;
   a.N = n; a.H = h; a.W = w; a.CW = cw; a.KS = ksize; a.sgn = sgn;
   a.prologue = prologue; a.groups = groups; a.eps = eps;
   a.inv_cnt = prologue ? 1.0f / ((float)(cw / groups) * (float)h * (float)w) : 0.f;

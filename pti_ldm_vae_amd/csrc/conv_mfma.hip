@@ -61,12 +61,12 @@ struct ConvArgs {
   const bf16* x;
   const unsigned char* w;
   const float* bias;
-  const float* in_stats;
+  const stat_t* in_stats;
   const float* gamma;
   const float* beta;
   const bf16* res;
   bf16* y;
-  float* out_stats;
+  stat_t* out_stats;
   int N, H, W, Cin, Ho, Wo, Cout;
   int mode, prologue, groups, out_groups;
   float eps, inv_cnt;
@@ -76,7 +76,7 @@ struct ConvArgs {
   int gn_mode;            // 0 off, 1 GN, 2 GN+SiLU
   int g_groups;
   float g_inv_cnt, g_eps;
-  const float* g_stats; const float* g_gamma; const float* g_beta;
+  const stat_t* g_stats; const float* g_gamma; const float* g_beta;
   float* g_sums;
   // optional side output (v2 kernel, PTI_CONV_S1 with a prologue): the activated input act(GN(x)) as bf16 NHWC,
   // written by the cout-tile-0 workgroups from their staging registers, for the weight-gradient pass to reuse
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
       for (int j = 0; j < 8; ++j) {
         const int ch = chunk * CK + lc * 8 + j;
         const int g = ch / cpg;
-        const float sum = a.in_stats[(n * a.groups + g) * 2], sq = a.in_stats[(n * a.groups + g) * 2 + 1];
+        const float sum = stat_f(a.in_stats, (n * a.groups + g) * 2), sq = stat_f(a.in_stats, (n * a.groups + g) * 2 + 1);
         const float mean = sum * a.inv_cnt;
         const float var = fmaxf(sq * a.inv_cnt - mean * mean, 0.f);
         const float rstd = rsqrtf(var + a.eps);
@@ -259,11 +259,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
 
   // ================= epilogue: bias, residual, store, optional GN statistics =================
   const int j = lane & 31;
-  float* sstat = reinterpret_cast<float*>(smem);  // [out_groups][2], reuse of the (now idle) halo
+  stat_t* sstat = reinterpret_cast<stat_t*>(smem);  // [out_groups][2] fixed-point, reuse of the (now idle) halo
   const bool do_stats = a.out_stats != nullptr;
   const int ocpg = do_stats ? a.Cout / a.out_groups : 1;
   if (do_stats) {
-    if (tid < 2 * a.out_groups) sstat[tid] = 0.f;
+    if (tid < 2 * a.out_groups) sstat[tid] = 0;
     __syncthreads();
   }
 #pragma unroll
@@ -311,8 +311,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
             }
             if (j == 0) {
               const int g = co / ocpg;
-              atomicAdd(&sstat[2 * g], s1);
-              atomicAdd(&sstat[2 * g + 1], s2);
+              stat_add(&sstat[2 * g], s1);
+              stat_add(&sstat[2 * g + 1], s2);
             }
           } else {  // ocpg == 2: two groups inside the quad
             float a1 = r0 + r1, a2 = r0 * r0 + r1 * r1, b1 = r2 + r3, b2 = r2 * r2 + r3 * r3;
@@ -325,10 +325,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
             }
             if (j == 0) {
               const int g = co / 2;
-              atomicAdd(&sstat[2 * g], a1);
-              atomicAdd(&sstat[2 * g + 1], a2);
-              atomicAdd(&sstat[2 * g + 2], b1);
-              atomicAdd(&sstat[2 * g + 3], b2);
+              stat_add(&sstat[2 * g], a1);
+              stat_add(&sstat[2 * g + 1], a2);
+              stat_add(&sstat[2 * g + 2], b1);
+              stat_add(&sstat[2 * g + 3], b2);
             }
           }
         }
@@ -338,7 +338,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
   if (do_stats) {
     __syncthreads();
     const int g0 = (ct * COUT_TILE) / ocpg, ng = COUT_TILE / ocpg;
-    if (tid < 2 * ng) atomicAdd(&a.out_stats[(n * a.out_groups + g0) * 2 + tid], sstat[2 * g0 + tid]);
+    if (tid < 2 * ng)
+      atomicAdd((unsigned long long*)&a.out_stats[(n * a.out_groups + g0) * 2 + tid], (unsigned long long)sstat[2 * g0 + tid]);
   }
 }
 
@@ -422,7 +423,7 @@ struct Cfg2 {
   // residual tile (or the GroupNorm input of the fused backward): its own LDS region, filled by LDS-DMA
   // (global_load_lds_dwordx4, no registers) at kernel start so that it shares the halo loads' round trip instead of
   // costing a second one in the epilogue.  Lane-linear image [pixel][CT/8 pieces], swizzled on the SOURCE side.
-  static constexpr int RT_OFF = STAT_OFF + 1024;
+  static constexpr int RT_OFF = STAT_OFF + 1024 + 256;   // accumulators (1 KiB) + float table of the input statistics
   static constexpr int RT_BYTES = MPX * CT * 2;
   static constexpr int LDS_BYTES = RT_OFF + RT_BYTES;
 };
@@ -470,6 +471,15 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
   constexpr int PSTEP = 256 / C::NC;
   const int cpg = a.Cin / (a.groups > 0 ? a.groups : 1);
   reinterpret_cast<float*>(smem + C::STAT_OFF)[tid] = 0.f;   // visible after the first barrier below
+  // this sample's GroupNorm sums (of the prologue's input, or of the fused backward's GN input) as floats in LDS:
+  // 2*G threads convert the fixed-point values once instead of every thread converting the ones its channels need
+  // (256 B behind the 1-KiB accumulator area, so groups <= 32)
+  float* sfl = reinterpret_cast<float*>(smem + C::STAT_OFF + 1024);
+  if (a.prologue != PTI_PRO_NONE) {
+    if (tid < 2 * a.groups) sfl[tid] = stat_f(a.in_stats, n * a.groups * 2 + tid);
+  } else if (a.gn_mode) {
+    if (tid < 2 * a.g_groups) sfl[tid] = stat_f(a.g_stats, n * a.g_groups * 2 + tid);
+  }
   if (a.res) {
     // piece (p, c) of the residual tile -> LDS slot p*ENC + c, holding channel piece c ^ ((p >> 2) & (ENC-1)) (the
     // epilogue reads apply the same XOR: 8-byte reads of one piece column at a 64..256-byte pixel pitch would
@@ -531,13 +541,14 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
     }
     // GroupNorm scale / shift of this thread's 8 channels: fetched AFTER the halo loads were issued, so that the
     // statistics / gamma / beta round trips (L2) overlap the halo's HBM round trip instead of preceding it
+    if (chunk == 0) __syncthreads();   // the float statistics table (sfl) is complete
     float sc[8], sh[8];
     if (a.prologue != PTI_PRO_NONE) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int ch = chunk * CK + lc * 8 + j;
         const int g = ch / cpg;
-        const float sum = a.in_stats[(n * a.groups + g) * 2], sq = a.in_stats[(n * a.groups + g) * 2 + 1];
+        const float sum = sfl[2 * g], sq = sfl[2 * g + 1];
         const float mean = sum * a.inv_cnt;
         const float rstd = rsqrtf(fmaxf(sq * a.inv_cnt - mean * mean, 0.f) + a.eps);
         sc[j] = rstd * a.gamma[ch];
@@ -669,7 +680,7 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int g = (ch0 + r) / gcpg;
-        const float sum = a.g_stats[(n * a.g_groups + g) * 2], sq = a.g_stats[(n * a.g_groups + g) * 2 + 1];
+        const float sum = sfl[2 * g], sq = sfl[2 * g + 1];
         const float mean = sum * a.g_inv_cnt;
         const float rstd = rsqrtf(fmaxf(sq * a.g_inv_cnt - mean * mean, 0.f) + a.g_eps);
         muv[r] = mean; rsv[r] = rstd;
@@ -754,7 +765,7 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
   }
   if (do_stats) {
     // fold the 32 pixel-lanes of each wave half (fold32), then LDS atomics: one lane per (channel quad, sum)
-    float* sstat = reinterpret_cast<float*>(smem + C::STAT_OFF);   // zeroed before the main loop
+    stat_t* sstat = reinterpret_cast<stat_t*>(smem + C::STAT_OFF);   // fixed-point; zeroed before the main loop
     if (ocpg >= 4) {
       float v[8];
 #pragma unroll
@@ -763,7 +774,7 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
       if ((j & 3) == 0) {
         const int idx = j >> 2, q = idx >> 1;
         const int g = (ct * CT + col0 + 8 * q) / ocpg;
-        atomicAdd(&sstat[2 * g + (idx & 1)], v[0]);
+        stat_add(&sstat[2 * g + (idx & 1)], v[0]);
       }
     } else {   // two channels per group: every quad spans two groups
       float v[16];
@@ -773,7 +784,7 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
       if ((j & 1) == 0) {
         const int idx = j >> 1, q = idx >> 2;
         const int g = (ct * CT + col0 + 8 * q) / 2;
-        atomicAdd(&sstat[2 * g + (idx & 3)], v[0]);
+        stat_add(&sstat[2 * g + (idx & 3)], v[0]);
       }
     }
   }
@@ -821,9 +832,10 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
     if (tid < 2 * CT)
       atomicAdd(&a.g_sums[((size_t)n * a.Cout + ct * CT) * 2 + tid], reinterpret_cast<float*>(smem + C::STAT_OFF)[tid]);
   } else if (do_stats) {
-    const float* sstat = reinterpret_cast<const float*>(smem + C::STAT_OFF);
+    const stat_t* sstat = reinterpret_cast<const stat_t*>(smem + C::STAT_OFF);
     const int g0 = (ct * CT) / ocpg, ng = CT / ocpg;   // one wave-instruction of global atomics per workgroup
-    if (tid < 2 * ng) atomicAdd(&a.out_stats[(n * a.out_groups + g0) * 2 + tid], sstat[2 * g0 + tid]);
+    if (tid < 2 * ng)
+      atomicAdd((unsigned long long*)&a.out_stats[(n * a.out_groups + g0) * 2 + tid], (unsigned long long)sstat[2 * g0 + tid]);
   }
 }
 
@@ -1015,11 +1027,11 @@ extern "C" int pti_conv_pack_weights_batched(const void* table_dev, const int* b
   return PTI_OK;
 }
 
-struct GnBwdFuse { int mode; const float* stats; const float* gamma; const float* beta; float* sums; };
+struct GnBwdFuse { int mode; const int64_t* stats; const float* gamma; const float* beta; float* sums; };
 
-static int conv2d_mfma_impl(const void* x, const void* w_packed, const float* bias, const float* in_stats,
+static int conv2d_mfma_impl(const void* x, const void* w_packed, const float* bias, const int64_t* in_stats,
                             const float* gamma, const float* beta, const void* residual, void* y,
-                            float* out_stats, const pti_conv_desc* d, const GnBwdFuse* gf, void* act_out,
+                            int64_t* out_stats, const pti_conv_desc* d, const GnBwdFuse* gf, void* act_out,
                             pti_stream_t s) {
   if (!x || !w_packed || !y || !d) PTI_FAIL(PTI_EINVAL, "conv2d_mfma: null pointer");
   if (act_out && (d->mode != PTI_CONV_S1 || d->prologue == PTI_PRO_NONE || d->ksize != 3))
@@ -1042,22 +1054,23 @@ static int conv2d_mfma_impl(const void* x, const void* w_packed, const float* bi
   if (d->prologue != PTI_PRO_NONE) {
     if (!in_stats || !gamma || !beta || d->groups <= 0 || d->cin % d->groups)
       PTI_FAIL(PTI_EINVAL, "conv2d_mfma: prologue needs stats/gamma/beta and groups | cin");
+    if (d->groups > 32) PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: prologue supports at most 32 groups");
   }
   if (d->add_residual && !residual) PTI_FAIL(PTI_EINVAL, "conv2d_mfma: add_residual without residual");
   if (d->accum_stats) {
     if (!out_stats || d->out_groups <= 0 || d->cout % d->out_groups) PTI_FAIL(PTI_EINVAL, "conv2d_mfma: bad out stats");
     const int ocpg = d->cout / d->out_groups;
     if (ocpg != 2 && (ocpg % 4 != 0 || ocpg > 32)) PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: channels/group %d for fused stats", ocpg);
-    if (2 * d->out_groups > 256) PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: too many out groups");
+    if (d->out_groups > 64) PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: fused statistics support at most 64 groups");
   }
   ConvArgs a;
-  a.x = (const bf16*)x; a.w = (const unsigned char*)w_packed; a.bias = bias; a.in_stats = in_stats;
+  a.x = (const bf16*)x; a.w = (const unsigned char*)w_packed; a.bias = bias; a.in_stats = (const stat_t*)in_stats;
   a.gamma = gamma; a.beta = beta; a.res = d->add_residual ? (const bf16*)residual : nullptr; a.y = (bf16*)y;
-  a.out_stats = d->accum_stats ? out_stats : nullptr;
+  a.out_stats = d->accum_stats ? (stat_t*)out_stats : nullptr;
   a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Ho = d->ho; a.Wo = d->wo; a.Cout = d->cout;
   a.mode = d->mode; a.prologue = d->prologue; a.groups = d->groups; a.out_groups = d->out_groups;
   a.gn_mode = 0; a.g_groups = 0; a.g_inv_cnt = 0.f; a.g_eps = 0.f;
-  a.g_stats = a.g_gamma = a.g_beta = nullptr; a.g_sums = nullptr;
+  a.g_stats = nullptr; a.g_gamma = a.g_beta = nullptr; a.g_sums = nullptr;
   a.act_out = (bf16*)act_out;
   a.in_f16 = d->in_f16; a.res_f16 = d->res_f16; a.out_f16 = d->out_f16;
   a.pool2 = d->pool2x2_out;
@@ -1066,9 +1079,10 @@ static int conv2d_mfma_impl(const void* x, const void* w_packed, const float* bi
   a.eps = d->eps;
   a.inv_cnt = d->prologue != PTI_PRO_NONE ? 1.0f / ((float)(d->cin / d->groups) * (float)d->h * (float)d->w) : 0.f;
   if (gf) {
+    if (d->groups > 32) PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma_gnbwd: at most 32 groups");
     a.gn_mode = gf->mode; a.g_groups = d->groups; a.g_eps = d->eps;
     a.g_inv_cnt = 1.0f / ((float)(d->cout / d->groups) * (float)d->ho * (float)d->wo);
-    a.g_stats = gf->stats; a.g_gamma = gf->gamma; a.g_beta = gf->beta; a.g_sums = gf->sums;
+    a.g_stats = (const stat_t*)gf->stats; a.g_gamma = gf->gamma; a.g_beta = gf->beta; a.g_sums = gf->sums;
   }
   a.tiles_x = cdiv(d->wo, TW); a.tiles_y = cdiv(d->ho, TH);
   const int cout_tile = pick_cout_tile(d->cout);
@@ -1085,20 +1099,20 @@ static int conv2d_mfma_impl(const void* x, const void* w_packed, const float* bi
   return PTI_OK;
 }
 
-extern "C" int pti_conv2d_mfma(const void* x, const void* w_packed, const float* bias, const float* in_stats,
+extern "C" int pti_conv2d_mfma(const void* x, const void* w_packed, const float* bias, const int64_t* in_stats,
                                const float* gamma, const float* beta, const void* residual, void* y,
-                               float* out_stats, const pti_conv_desc* d, pti_stream_t s) {
+                               int64_t* out_stats, const pti_conv_desc* d, pti_stream_t s) {
   return conv2d_mfma_impl(x, w_packed, bias, in_stats, gamma, beta, residual, y, out_stats, d, nullptr, nullptr, s);
 }
 
-extern "C" int pti_conv2d_mfma_saveact(const void* x, const void* w_packed, const float* bias, const float* in_stats,
+extern "C" int pti_conv2d_mfma_saveact(const void* x, const void* w_packed, const float* bias, const int64_t* in_stats,
                                        const float* gamma, const float* beta, const void* residual, void* y,
-                                       float* out_stats, void* act_out, const pti_conv_desc* d, pti_stream_t s) {
+                                       int64_t* out_stats, void* act_out, const pti_conv_desc* d, pti_stream_t s) {
   if (!act_out) PTI_FAIL(PTI_EINVAL, "conv2d_mfma_saveact: null act_out");
   return conv2d_mfma_impl(x, w_packed, bias, in_stats, gamma, beta, residual, y, out_stats, d, nullptr, act_out, s);
 }
 
-extern "C" int pti_conv2d_mfma_gnbwd(const void* dy_in, const void* w_packed, const void* gx, const float* gstats,
+extern "C" int pti_conv2d_mfma_gnbwd(const void* dy_in, const void* w_packed, const void* gx, const int64_t* gstats,
                                      const float* ggamma, const float* gbeta, void* dy_out, float* gsums,
                                      const pti_conv_desc* d, int silu, pti_stream_t s) {
   if (!gx || !gstats || !ggamma || !gbeta || !gsums || !d) PTI_FAIL(PTI_EINVAL, "conv2d_mfma_gnbwd: null pointer");

@@ -9,15 +9,16 @@
 namespace {
 
 // stats[n][g] += {sum, sumsq}.  grid = (blocks_per_sample, N), block = 256.
-__global__ __launch_bounds__(256) void gn_stats_kernel(const bf16* __restrict__ x, float* __restrict__ stats,
+__global__ __launch_bounds__(256) void gn_stats_kernel(const bf16* __restrict__ x, stat_t* __restrict__ stats,
                                                        int HW, int C, int G, int pix_per_block, int x_f16) {
-  extern __shared__ float sm[];  // [G][2]
+  extern __shared__ stat_t sm_q[];  // [G][2] fixed-point
+  stat_t* sm = sm_q;
   const int n = blockIdx.y;
   const int tid = threadIdx.x;
   const int NC = C / 8;
   const int ppi = 256 / NC;  // pixels per iteration (NC divides 256 for C in {32..2048} powers of two)
   const int lc = tid % NC, lp = tid / NC;
-  for (int i = tid; i < 2 * G; i += 256) sm[i] = 0.f;
+  for (int i = tid; i < 2 * G; i += 256) sm[i] = 0;
   __syncthreads();
   const int p0 = blockIdx.x * pix_per_block;
   const int p1 = min(p0 + pix_per_block, HW);
@@ -64,25 +65,26 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16* __restrict__ 
 #pragma unroll
       for (int j = 0; j < 8; ++j) { a += s[j]; b += q[j]; }
       const int g = (lc * 8) / cpg;
-      atomicAdd(&sm[2 * g], a);
-      atomicAdd(&sm[2 * g + 1], b);
+      stat_add(&sm[2 * g], a);
+      stat_add(&sm[2 * g + 1], b);
     } else {
       for (int j0 = 0; j0 < 8; j0 += cpg) {
         float a = 0.f, b = 0.f;
         for (int j = j0; j < j0 + cpg; ++j) { a += s[j]; b += q[j]; }
         const int g = (lc * 8 + j0) / cpg;
-        atomicAdd(&sm[2 * g], a);
-        atomicAdd(&sm[2 * g + 1], b);
+        stat_add(&sm[2 * g], a);
+        stat_add(&sm[2 * g + 1], b);
       }
     }
   }
   __syncthreads();
-  for (int i = tid; i < 2 * G; i += 256) atomicAdd(&stats[(size_t)n * G * 2 + i], sm[i]);
+  for (int i = tid; i < 2 * G; i += 256)
+    atomicAdd((unsigned long long*)&stats[(size_t)n * G * 2 + i], (unsigned long long)sm[i]);
 }
 
 }  // namespace
 
-extern "C" int pti_gn_stats(const void* x, float* stats, int n, int hw, int c, int groups, int x_f16, pti_stream_t s) {
+extern "C" int pti_gn_stats(const void* x, int64_t* stats, int n, int hw, int c, int groups, int x_f16, pti_stream_t s) {
   if (!x || !stats || n <= 0 || hw <= 0) PTI_FAIL(PTI_EINVAL, "gn_stats: bad pointer/dims");
   if (c < 8 || c > 2048 || (c & (c - 1)) || groups <= 0 || c % groups)
     PTI_FAIL(PTI_EUNSUPPORTED, "gn_stats: c=%d must be a power of two in [8,2048] and divisible by groups=%d", c, groups);
@@ -97,8 +99,8 @@ extern "C" int pti_gn_stats(const void* x, float* stats, int n, int hw, int c, i
   if (ppb < 16 * ppi) ppb = 16 * ppi;
   ppb = cdiv(ppb, 4 * ppi) * 4 * ppi;
   bps = cdiv(hw, ppb);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(bps, n), dim3(256), 2 * groups * sizeof(float), (hipStream_t)s,
-                     (const bf16*)x, stats, hw, c, groups, ppb, x_f16);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(bps, n), dim3(256), 2 * groups * sizeof(stat_t), (hipStream_t)s,
+                     (const bf16*)x, (stat_t*)stats, hw, c, groups, ppb, x_f16);
   PTI_CHECK_LAUNCH("gn_stats");
   return PTI_OK;
 }
@@ -114,7 +116,7 @@ namespace {
 
 struct GnbArgs {
   const bf16* x; const bf16* da; const bf16* dres; bf16* dx;
-  const float* stats; const float* gamma; const float* beta;
+  const stat_t* stats; const float* gamma; const float* beta;
   float* sums;   // [N][C][2]
   float* dgamma; float* dbeta;
   int HW, C, G, silu, ppb;
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnbArgs a) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int ch = lc * 8 + j, g = ch / cpg;
-    const float sum = a.stats[(n * a.G + g) * 2], sq = a.stats[(n * a.G + g) * 2 + 1];
+    const float sum = stat_f(a.stats, (n * a.G + g) * 2), sq = stat_f(a.stats, (n * a.G + g) * 2 + 1);
     const float mean = sum * a.inv_cnt;
     const float rstd = rsqrtf(fmaxf(sq * a.inv_cnt - mean * mean, 0.f) + a.eps);
     mu[j] = mean; rs[j] = rstd;
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnbArgs a) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int ch = lc * 8 + j, g = ch / cpg;
-    const float sum = a.stats[(n * a.G + g) * 2], sq = a.stats[(n * a.G + g) * 2 + 1];
+    const float sum = stat_f(a.stats, (n * a.G + g) * 2), sq = stat_f(a.stats, (n * a.G + g) * 2 + 1);
     const float mean = sum * a.inv_cnt;
     const float rstd = rsqrtf(fmaxf(sq * a.inv_cnt - mean * mean, 0.f) + a.eps);
     mu[j] = mean; rs[j] = rstd; ga[j] = a.gamma[ch];
@@ -308,14 +310,14 @@ __global__ __launch_bounds__(256) void pool2x2_sum_kernel(const bf16* __restrict
 
 }  // namespace
 
-extern "C" int pti_gn_bwd(const void* x, const void* da, const void* dres, void* dx, const float* stats,
+extern "C" int pti_gn_bwd(const void* x, const void* da, const void* dres, void* dx, const int64_t* stats,
                           const float* gamma, const float* beta, float* sums, float* dgamma, float* dbeta, int n,
                           int hw, int c, int groups, float eps, int silu, int x_f16, pti_stream_t s) {
   if (!x || !da || !dx || !stats || !gamma || !beta || !sums) PTI_FAIL(PTI_EINVAL, "gn_bwd: null pointer");
   if (c < 8 || c > 2048 || (c & (c - 1)) || groups <= 0 || c % groups) PTI_FAIL(PTI_EUNSUPPORTED, "gn_bwd: c=%d groups=%d", c, groups);
   GnbArgs a;
   a.x = (const bf16*)x; a.da = (const bf16*)da; a.dres = (const bf16*)dres; a.dx = (bf16*)dx;
-  a.stats = stats; a.gamma = gamma; a.beta = beta; a.sums = sums; a.dgamma = dgamma; a.dbeta = dbeta;
+  a.stats = (const stat_t*)stats; a.gamma = gamma; a.beta = beta; a.sums = sums; a.dgamma = dgamma; a.dbeta = dbeta;
   a.HW = hw; a.C = c; a.G = groups; a.silu = silu; a.eps = eps; a.x_f16 = x_f16;
   a.inv_cnt = 1.0f / ((float)(c / groups) * (float)hw);
   const int ppi = 256 / (c / 8);
@@ -334,14 +336,14 @@ extern "C" int pti_gn_bwd(const void* x, const void* da, const void* dres, void*
 
 // second half only: `dy` already is dA * act'(GN(x)) and `sums` already holds {sum dy, sum dy*xhat} per (n,c)
 // (both produced by pti_conv2d_mfma_gnbwd in the data-gradient conv's epilogue)
-extern "C" int pti_gn_bwd_apply(const void* x, const void* dy, const void* dres, void* dx, const float* stats,
+extern "C" int pti_gn_bwd_apply(const void* x, const void* dy, const void* dres, void* dx, const int64_t* stats,
                                 const float* gamma, const float* beta, const float* sums, float* dgamma, float* dbeta,
                                 int n, int hw, int c, int groups, float eps, int x_f16, pti_stream_t s) {
   if (!x || !dy || !dx || !stats || !gamma || !beta || !sums) PTI_FAIL(PTI_EINVAL, "gn_bwd_apply: null pointer");
   if (c < 8 || c > 2048 || (c & (c - 1)) || groups <= 0 || c % groups) PTI_FAIL(PTI_EUNSUPPORTED, "gn_bwd_apply: c=%d groups=%d", c, groups);
   GnbArgs a;
   a.x = (const bf16*)x; a.da = (const bf16*)dy; a.dres = (const bf16*)dres; a.dx = (bf16*)dx;
-  a.stats = stats; a.gamma = gamma; a.beta = beta; a.sums = const_cast<float*>(sums); a.dgamma = dgamma; a.dbeta = dbeta;
+  a.stats = (const stat_t*)stats; a.gamma = gamma; a.beta = beta; a.sums = const_cast<float*>(sums); a.dgamma = dgamma; a.dbeta = dbeta;
   a.HW = hw; a.C = c; a.G = groups; a.silu = 0; a.eps = eps; a.x_f16 = x_f16;
   a.inv_cnt = 1.0f / ((float)(c / groups) * (float)hw);
   const int ppi = 256 / (c / 8);

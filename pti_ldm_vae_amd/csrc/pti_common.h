@@ -62,6 +62,23 @@ __device__ __forceinline__ u32x2 pack4(float a, float b, float c, float d) {
   r[1] = __builtin_bit_cast(uint32_t, p1);
   return r;
 }
+// ---- GroupNorm statistics ---------------------------------------------------------------------------
+// {sum, sum of squares} per (sample, group) are accumulated as 64-bit FIXED-POINT integers (Q47.16): integer adds are
+// associative, so the totals -- and with them every kernel that normalises by them -- are bitwise reproducible no
+// matter in which order workgroups and waves arrive.  (Float atomics made two runs on identical inputs differ by the
+// full bf16 rounding noise, 1.6e-2 relative on the reconstruction: the low bits of a mean flip roundings downstream.)
+// Per-lane / per-wave partial sums stay fp32 in a fixed order; they are quantised to 2^-16 once, when they enter the
+// shared accumulator.  Range: |sum of squares| < 2^47 = 1.4e14.
+typedef long long stat_t;
+__device__ __forceinline__ unsigned long long stat_q(float v) { return (unsigned long long)__float2ll_rn(v * 65536.0f); }
+// value / 2^16 as fp32 from the two 32-bit halves (4 VALU ops; the int64 -> double -> float route cost ~3x as many
+// and showed up as +20 % on the VALU-bound 32-channel convs)
+__device__ __forceinline__ float stat_f(const stat_t* p, int i) {
+  const long long v = p[i];
+  return (float)(int)(v >> 32) * 65536.0f + (float)(unsigned)v * (1.0f / 65536.0f);
+}
+__device__ __forceinline__ void stat_add(stat_t* p, float v) { atomicAdd((unsigned long long*)p, stat_q(v)); }
+
 // ---- 16-bit activation formats -----------------------------------------------------------------
 // Activations written by the FORWARD pass may be stored as IEEE fp16 (11-bit significand) instead of bf16: same
 // bytes, 8x smaller rounding step, and GroupNorm keeps their range far inside fp16's.  MFMA operands, saved

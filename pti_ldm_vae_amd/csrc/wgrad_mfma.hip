@@ -20,7 +20,7 @@ constexpr int TH = 8, TW = 16;
 struct WgArgs {
   const bf16* x;
   const bf16* dy;
-  const float* in_stats;
+  const stat_t* in_stats;
   const float* gamma;
   const float* beta;
   float* slab;  // [S][KK*Cout*Cin + Cout]
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgArgs a) {
       for (int j = 0; j < 8; ++j) {
         const int ch = cit * CI_T + alc * 8 + j;
         const int gg = ch / cpg;
-        const float sum = a.in_stats[(n * a.groups + gg) * 2], sq = a.in_stats[(n * a.groups + gg) * 2 + 1];
+        const float sum = stat_f(a.in_stats, (n * a.groups + gg) * 2), sq = stat_f(a.in_stats, (n * a.groups + gg) * 2 + 1);
         const float mean = sum * a.inv_cnt;
         const float rstd = rsqrtf(fmaxf(sq * a.inv_cnt - mean * mean, 0.f) + a.eps);
         sc[j] = rstd * a.gamma[ch];
@@ -282,7 +282,7 @@ struct W3Cfg {
   static constexpr int LDS_BYTES = A_BYTES + D_BYTES;
 };
 
-__global__ __launch_bounds__(192) void wgrad_mfma3_kernel(WgArgs a) {
+__global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3, 3))) void wgrad_mfma3_kernel(WgArgs a) {   // 3 waves/SIMD: <= 168 VGPR+AGPR
   using C = W3Cfg;
   typedef short v4s __attribute__((ext_vector_type(4)));
   typedef short v8s __attribute__((ext_vector_type(8)));
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(192) void wgrad_mfma3_kernel(WgArgs a) {
       for (int j = 0; j < 8; ++j) {
         const int ch = cit * 32 + lc * 8 + j;
         const int gg = ch / cpg;
-        const float sum = a.in_stats[(n * a.groups + gg) * 2], sq = a.in_stats[(n * a.groups + gg) * 2 + 1];
+        const float sum = stat_f(a.in_stats, (n * a.groups + gg) * 2), sq = stat_f(a.in_stats, (n * a.groups + gg) * 2 + 1);
         const float mean = sum * a.inv_cnt;
         const float rstd = rsqrtf(fmaxf(sq * a.inv_cnt - mean * mean, 0.f) + a.eps);
         sc[j] = rstd * a.gamma[ch];
@@ -529,7 +529,7 @@ extern "C" int64_t pti_conv_wgrad_workspace_bytes(int cout, int cin, int ksize, 
   return (int64_t)splits * ((int64_t)ksize * ksize * cout * cin + cout) * 4;
 }
 
-static int wgrad_check(const void* x, const void* dy, const float* in_stats, const float* gamma, const float* beta,
+static int wgrad_check(const void* x, const void* dy, const int64_t* in_stats, const float* gamma, const float* beta,
                        const void* workspace, const pti_conv_desc* d) {
   if (!x || !dy || !workspace || !d) PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma: null pointer");
   if (d->cin % 32 || d->cout % 32) PTI_FAIL(PTI_EUNSUPPORTED, "conv_wgrad_mfma: cin=%d cout=%d", d->cin, d->cout);
@@ -540,13 +540,13 @@ static int wgrad_check(const void* x, const void* dy, const float* in_stats, con
   return PTI_OK;
 }
 
-extern "C" int pti_conv_wgrad_mfma_partials(const void* x, const void* dy, const float* in_stats, const float* gamma,
+extern "C" int pti_conv_wgrad_mfma_partials(const void* x, const void* dy, const int64_t* in_stats, const float* gamma,
                                             const float* beta, void* workspace, int64_t workspace_bytes,
                                             const pti_conv_desc* d, int* splits_out, pti_stream_t s) {
   if (!splits_out) PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma_partials: null splits_out");
   if (int rc = wgrad_check(x, dy, in_stats, gamma, beta, workspace, d)) return rc;
   WgArgs a;
-  a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.in_stats = in_stats; a.gamma = gamma; a.beta = beta;
+  a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.in_stats = (const stat_t*)in_stats; a.gamma = gamma; a.beta = beta;
   a.slab = (float*)workspace;
   a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Ho = d->ho; a.Wo = d->wo; a.Cout = d->cout;
   a.mode = d->mode; a.prologue = d->prologue; a.groups = d->groups; a.eps = d->eps; a.x_f16 = d->in_f16;
@@ -594,7 +594,7 @@ extern "C" int pti_conv_wgrad_reduce(const void* workspace, int splits, float* d
   return PTI_OK;
 }
 
-extern "C" int pti_conv_wgrad_mfma(const void* x, const void* dy, const float* in_stats, const float* gamma,
+extern "C" int pti_conv_wgrad_mfma(const void* x, const void* dy, const int64_t* in_stats, const float* gamma,
                                    const float* beta, float* dw, float* dbias, void* workspace,
                                    int64_t workspace_bytes, int accumulate, const pti_conv_desc* d, pti_stream_t s) {
   if (!dw) PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma: null pointer");

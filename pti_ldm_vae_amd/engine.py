@@ -371,7 +371,8 @@ class Engine:
 
     # ---- helpers -------------------------------------------------------------------------------
     def new_stats(self, n):
-        return self.zeros(n * self.G * 2).view(n, self.G, 2)
+        """Zeroed GroupNorm statistics [n, G, 2]: fixed-point int64 sums (see pti_common.h), carved from the fp32 pool."""
+        return self.zeros(n * self.G * 4).view(torch.int64).view(n, self.G, 2)
 
     def zeros(self, count):
         """Zero-initialised fp32 scratch carved from one pool per pass (one memset instead of ~100 fills)."""

@@ -17,6 +17,8 @@ from ._lib import (PTI_CONV_S1, PTI_CONV_S2PAD, PTI_CONV_UP2, PTI_CONV_ZINS, PTI
 BF16 = torch.bfloat16
 F16 = torch.float16
 F32 = torch.float32
+I64 = torch.int64
+STAT_SCALE = 65536.0   # GroupNorm statistics are Q47.16 fixed-point int64 {sum, sum of squares} (pti_common.h)
 ACT16 = (BF16, F16)   # storage formats of a forward activation (flag derived from the tensor's dtype)
 
 
@@ -69,16 +71,25 @@ def pack_conv_weight(ws, ksize, mode=PTI_CONV_S1, flip=False, out=None):
     return out
 
 
+def _chk_stats(t, count, name):
+    _chk(t, I64, name)
+    if t.numel() != count:
+        raise ValueError(f"{name}: expected {count} fixed-point sums, got {t.numel()}")
+
+
+def stats_to_float(stats):
+    """Fixed-point {sum, sumsq} -> float64 tensor of the same shape (tests, diagnostics)."""
+    return stats.double() / STAT_SCALE
+
+
 def gn_stats(x, groups, stats=None):
-    """x: [N,H,W,C] bf16|fp16 -> stats [N,G,2] fp32 {sum, sumsq} (accumulated into ``stats`` if given)."""
+    """x: [N,H,W,C] bf16|fp16 -> stats [N,G,2] int64 Q47.16 {sum, sumsq} (accumulated into ``stats`` if given)."""
     _chk(x, ACT16, "x", 4)
     n, h, w, c = x.shape
     if stats is None:
-        stats = torch.zeros(n, groups, 2, dtype=F32, device=x.device)
+        stats = torch.zeros(n, groups, 2, dtype=I64, device=x.device)
     else:
-        _chk(stats, F32, "stats")
-        if stats.numel() != n * groups * 2:
-            raise ValueError("gn_stats: stats size")
+        _chk_stats(stats, n * groups * 2, "stats")
     L.check(L.lib().pti_gn_stats(_ptr(x), _ptr(stats), n, h * w, c, groups, int(x.dtype == F16), _stream()),
             "pti_gn_stats")
     return stats
@@ -107,7 +118,8 @@ def conv_mfma(x, w_packed, bias, y, *, cout, ksize=3, mode=PTI_CONV_S1, prologue
         if bias.numel() != cout:
             raise ValueError("conv_mfma: bias size")
     if prologue != PTI_PRO_NONE:
-        for t, nm, cnt in ((in_stats, "in_stats", n * groups * 2), (gamma, "gamma", cin), (beta, "beta", cin)):
+        _chk_stats(in_stats, n * groups * 2, "in_stats")
+        for t, nm, cnt in ((gamma, "gamma", cin), (beta, "beta", cin)):
             _chk(t, F32, nm)
             if t.numel() != cnt:
                 raise ValueError(f"conv_mfma: {nm} size")
@@ -116,9 +128,7 @@ def conv_mfma(x, w_packed, bias, y, *, cout, ksize=3, mode=PTI_CONV_S1, prologue
         if residual.shape != y.shape or pool2:
             raise ValueError("conv_mfma: residual shape")
     if out_stats is not None:
-        _chk(out_stats, F32, "out_stats")
-        if out_stats.numel() != n * out_groups * 2:
-            raise ValueError("conv_mfma: out_stats size")
+        _chk_stats(out_stats, n * out_groups * 2, "out_stats")
     d = ConvDesc(n=n, h=h, w=w, cin=cin, ho=ho, wo=wo, cout=cout, ksize=ksize, mode=mode, prologue=prologue,
                  groups=groups, add_residual=int(residual is not None), accum_stats=int(out_stats is not None),
                  out_groups=out_groups, eps=eps, in_f16=int(x.dtype == F16),
@@ -176,6 +186,8 @@ def conv_direct(x, w_tck, bias, y, *, n, h, w, cin, cout, ksize=3, x_layout="nhw
         raise ValueError("conv_direct: weight size")
     if x.numel() != n * h * w * cin or y.numel() != n * h * w * cout:
         raise ValueError("conv_direct: tensor sizes do not match n,h,w,cin,cout")
+    if prologue != PTI_PRO_NONE:
+        _chk_stats(in_stats, n * groups * 2, "in_stats")
     d = ConvDesc(n=n, h=h, w=w, cin=cin, ho=h, wo=w, cout=cout, ksize=ksize, mode=PTI_CONV_S1, prologue=prologue,
                  groups=groups, eps=eps, in_f32=int(x.dtype == F32), out_f32=int(y.dtype == F32),
                  in_f16=int(x.dtype == F16), out_f16=int(y.dtype == F16))
@@ -199,6 +211,8 @@ def wgrad_direct(wide, narrow, dw, *, n, h, w, cw, cn, ksize, sgn, narrow_layout
     strides into the fp32 OIHW gradient ``dw`` (must be zero-initialised or hold a running sum)."""
     _chk(wide, ACT16, "wide", 4)
     _chk(dw, F32, "dw")
+    if prologue != PTI_PRO_NONE:
+        _chk_stats(in_stats, n * groups * 2, "in_stats")
     ns = (C.c_int64 * 4)(*_strides4(narrow, narrow_layout))
     ws = workspace if workspace is not None else wgrad_workspace(wide.device)
     L.check(L.lib().pti_wgrad_direct(_ptr(wide), _ptr(narrow), _ptr(dw), _ptr(dbias_wide), _ptr(dbias_narrow),
@@ -239,7 +253,8 @@ def conv_wgrad_mfma(x, dy, dw, dbias, *, ksize=3, mode=PTI_CONV_S1, prologue=PTI
         if dbias.numel() != cout:
             raise ValueError("conv_wgrad_mfma: dbias size")
     if prologue != PTI_PRO_NONE:
-        for t, nm, cnt in ((in_stats, "in_stats", n * groups * 2), (gamma, "gamma", cin), (beta, "beta", cin)):
+        _chk_stats(in_stats, n * groups * 2, "in_stats")
+        for t, nm, cnt in ((gamma, "gamma", cin), (beta, "beta", cin)):
             _chk(t, F32, nm)
             if t.numel() != cnt:
                 raise ValueError(f"conv_wgrad_mfma: {nm} size")
@@ -287,7 +302,8 @@ def gn_bwd(x, da, dx, stats, gamma, beta, sums, dgamma, dbeta, *, groups, eps=1e
     n, h, w, c = x.shape
     if da.shape != x.shape or dx.shape != x.shape or (dres is not None and dres.shape != x.shape):
         raise ValueError("gn_bwd: shape mismatch")
-    if sums.numel() != n * c * 2 or stats.numel() != n * groups * 2:
+    _chk_stats(stats, n * groups * 2, "stats")
+    if sums.numel() != n * c * 2:
         raise ValueError("gn_bwd: scratch sizes")
     L.check(L.lib().pti_gn_bwd(_ptr(x), _ptr(da), _ptr(dres), _ptr(dx), _ptr(stats), _ptr(gamma), _ptr(beta),
                                _ptr(sums), _ptr(dgamma), _ptr(dbeta), n, h * w, c, groups, eps, int(silu),
@@ -306,7 +322,8 @@ def conv_mfma_gnbwd(dy_in, w_packed_t, gx, gstats, ggamma, gbeta, dy_out, gsums,
     ho, wo = conv_out_hw(h, w, mode)
     if tuple(dy_out.shape) != (n, ho, wo, cout) or gx.shape != dy_out.shape:
         raise ValueError("conv_mfma_gnbwd: shapes")
-    if gsums.numel() != n * cout * 2 or gstats.numel() != n * groups * 2 or ggamma.numel() != cout:
+    _chk_stats(gstats, n * groups * 2, "gstats")
+    if gsums.numel() != n * cout * 2 or ggamma.numel() != cout:
         raise ValueError("conv_mfma_gnbwd: GroupNorm buffers")
     d = ConvDesc(n=n, h=h, w=w, cin=cin, ho=ho, wo=wo, cout=cout, ksize=ksize, mode=mode, groups=groups, eps=eps,
                  res_f16=int(gx.dtype == F16))
@@ -332,6 +349,7 @@ def gn_bwd_apply(x, dy, dx, stats, gamma, beta, sums, dgamma, dbeta, *, groups, 
     n, h, w, c = x.shape
     if dy.shape != x.shape or dx.shape != x.shape or (dres is not None and dres.shape != x.shape):
         raise ValueError("gn_bwd_apply: shape mismatch")
+    _chk_stats(stats, n * groups * 2, "stats")
     L.check(L.lib().pti_gn_bwd_apply(_ptr(x), _ptr(dy), _ptr(dres), _ptr(dx), _ptr(stats), _ptr(gamma), _ptr(beta),
                                      _ptr(sums), _ptr(dgamma), _ptr(dbeta), n, h * w, c, groups, eps,
                                      int(x.dtype == F16), _stream()), "pti_gn_bwd_apply")

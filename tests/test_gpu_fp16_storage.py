@@ -58,7 +58,7 @@ def test_conv_mfma_fp16_storage(dev, n, cin, cout, h, w, ks, mode, pro, res, ost
     ho, wo = ops.conv_out_hw(h, w, m)
     y = torch.full((n, ho, wo, cout), float("nan"), dtype=out_dt, device=dev)
     st = ops.gn_stats(xd, groups) if pro else None
-    ost = torch.zeros(n, 16, 2, device=dev) if ostats else None
+    ost = torch.zeros(n, 16, 2, dtype=torch.int64, device=dev) if ostats else None
     act = torch.full((n, h, w, cin), float("nan"), dtype=B16, device=dev) if (pro and mode == "s1" and ks == 3) else None
     ops.conv_mfma(xd, wp, bias.to(dev), y, cout=cout, ksize=ks, mode=m, prologue=pro, in_stats=st,
                   gamma=gamma.to(dev) if pro else None, beta=beta.to(dev) if pro else None, groups=groups, eps=eps,
@@ -69,7 +69,7 @@ def test_conv_mfma_fp16_storage(dev, n, cin, cout, h, w, ks, mode, pro, res, ost
     _report(f"conv_mfma fp16[{mode},k{ks},{cin}->{cout},pro{pro}]", got, ref, max_frac=2e-3 if tight else 1e-2,
             l2=5e-4 if tight else 3e-3)
     if ostats:   # statistics are those of the values as stored
-        _report("fused stats (fp16 out)", ost, _stats_ref(got, 16), max_frac=1e-3, l2=1e-4)
+        _report("fused stats (fp16 out)", ops.stats_to_float(ost), _stats_ref(got, 16), max_frac=1e-3, l2=1e-4)
     if act is not None:   # the saved activated input stays bf16 (it is the weight gradient's MFMA operand)
         _report("act_out (bf16)", act.float().cpu().permute(0, 3, 1, 2), a, max_frac=1e-2, l2=3e-3)
 
@@ -80,7 +80,7 @@ def test_gn_stats_fp16(dev):
     x = _r(torch.randn(3, 64, 9, 7) * 2 + 0.5)
     st = ops.gn_stats(_nhwc(x).to(dev, H16), 16)
     torch.cuda.synchronize()
-    _report("gn_stats fp16", st, _stats_ref(x, 16), max_frac=1e-4, l2=1e-5)
+    _report("gn_stats fp16", ops.stats_to_float(st), _stats_ref(x, 16), max_frac=1e-4, l2=1e-5)
 
 
 @pytest.mark.parametrize("n,c,h,w,silu,res", [(2, 32, 16, 16, True, True), (2, 128, 8, 8, False, False)])

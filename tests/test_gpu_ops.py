@@ -58,7 +58,7 @@ def test_gn_stats(dev, n, c, h, w, g):
     x = _r(torch.randn(n, c, h, w) * 1.5 + 0.3)
     st = ops.gn_stats(_nhwc(x).to(dev, torch.bfloat16), g)
     torch.cuda.synchronize()
-    _report("gn_stats", st, _stats_ref(x, g), max_frac=1e-4, l2=1e-5)
+    _report("gn_stats", ops.stats_to_float(st), _stats_ref(x, g), max_frac=1e-4, l2=1e-5)
 
 
 CONV_CASES = [
@@ -129,7 +129,7 @@ def test_conv_mfma(dev, n, cin, cout, h, w, ks, mode, pro, res, ostats):
     y = torch.full((n, ho, wo, cout), float("nan"), dtype=torch.bfloat16, device=dev)
     st = ops.gn_stats(xd, groups) if pro else None
     og = 16
-    ost = torch.zeros(n, og, 2, device=dev) if ostats else None
+    ost = torch.zeros(n, og, 2, dtype=torch.int64, device=dev) if ostats else None   # Q47.16 fixed-point sums
     # 3x3 S1 + prologue launches also exercise the side output act_out = prologue(x) (pti_conv2d_mfma_saveact)
     act = torch.full_like(xd, float("nan")) if (pro and mode == "s1" and ks == 3) else None
     ops.conv_mfma(xd, wp, bias.to(dev), y, cout=cout, ksize=ks, mode=m, prologue=pro, in_stats=st,
@@ -141,7 +141,7 @@ def test_conv_mfma(dev, n, cin, cout, h, w, ks, mode, pro, res, ostats):
     if act is not None:   # bf16 of an fp32 GN+SiLU: one rounding step of slack against the CPU reference
         _report("conv_mfma act_out", act.float().cpu().permute(0, 3, 1, 2), a, max_frac=1e-2, l2=3e-3)
     if ostats:
-        _report("conv_mfma fused stats", ost, _stats_ref(_r(got), og), max_frac=1e-3, l2=1e-4)
+        _report("conv_mfma fused stats", ops.stats_to_float(ost), _stats_ref(_r(got), og), max_frac=1e-3, l2=1e-4)
 
 
 def test_conv_mfma_rejects_bad_shapes(dev):

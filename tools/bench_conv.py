@@ -44,7 +44,7 @@ def main():
         y = torch.empty(B, ho, wo, cout, dtype=torch.bfloat16, device=dev)
         res = torch.randn_like(y)
         st = ops.gn_stats(x, G)
-        ost = torch.zeros(B, G, 2, device=dev)
+        ost = torch.zeros(B, G, 2, dtype=torch.int64, device=dev)
         flops = 2.0 * B * ho * wo * cout * cin * 9
         nbytes = 2.0 * (x.numel() + y.numel())
         tag = f"{cin:3d}->{cout:3d} @{h}x{w} mode{mode}"

@@ -34,7 +34,7 @@ for (cin, cout, s) in ((32, 32, 128), (64, 64, 64), (128, 128, 32), (64, 32, 128
     def fwd():
         y = torch.empty(B, s, s, cout, dtype=torch.float16, device=dev)
         a = torch.empty(B, s, s, cin, dtype=torch.bfloat16, device=dev)
-        ost = torch.zeros(B, G, 2, device=dev)
+        ost = torch.zeros(B, G, 2, dtype=torch.int64, device=dev)
         ops.conv_mfma(x, wp, bias, y, cout=cout, prologue=2, in_stats=st, gamma=gamma, beta=beta, groups=G, residual=res,
                       out_stats=ost, out_groups=G, act_out=a)
         return y, a

@@ -22,7 +22,7 @@ kw = {}
 if variant in ("gn", "full"):
     kw.update(prologue=2, in_stats=ops.gn_stats(x, G), gamma=torch.ones(cin, device=dev), beta=torch.zeros(cin, device=dev), groups=G)
 if variant == "full":
-    kw.update(residual=torch.randn_like(y), out_stats=torch.zeros(B, G, 2, device=dev), out_groups=G)
+    kw.update(residual=torch.randn_like(y), out_stats=torch.zeros(B, G, 2, dtype=torch.int64, device=dev), out_groups=G)
 for _ in range(5):
     ops.conv_mfma(x, wp, torch.zeros(cout, device=dev), y, cout=cout, mode=mode, **kw)
 torch.cuda.synchronize()
