@@ -156,18 +156,29 @@ int pti_conv_wgrad_reduce(const void* workspace, int splits, float* dw, float* d
                           int accumulate, const pti_conv_desc* d, pti_stream_t s);
 
 /* ---- GroupNorm(+SiLU) backward, 2x2 sum pool ---------------------------------------------- */
-/* dx = d/dx of act(GroupNorm(x)) given da (+ dres added), dgamma/dbeta += ; sums: zeroed float
- * [n][c][2] scratch; stats as produced by pti_gn_stats on x.  (autograd of nn.GroupNorm+F.silu) */
+/* dx = d/dx of act(GroupNorm(x)) given da (+ dres added), dgamma/dbeta += ; sums: float [n][c][2] scratch
+ * (written, need not be zeroed); partials: float scratch of n * pti_gn_bwd_blocks(n, hw, c) * c * 2 elements;
+ * stats as produced by pti_gn_stats on x.  (autograd of nn.GroupNorm+F.silu)
+ * No floating-point atomics anywhere on this path: every workgroup stores its partial {sum dy, sum dy*xhat} row,
+ * pti_gn_sums_finalize's kernel adds the rows in a fixed order and ONE workgroup of the apply kernel folds the
+ * samples into dgamma / dbeta, so the backward pass is bitwise reproducible run to run.          */
+int pti_gn_bwd_blocks(int n, int hw, int c);
 int pti_gn_bwd(const void* x, const void* da, const void* dres, void* dx, const int64_t* stats,
-               const float* gamma, const float* beta, float* sums, float* dgamma, float* dbeta,
-               int n, int hw, int c, int groups, float eps, int silu, int x_f16, pti_stream_t s);
+               const float* gamma, const float* beta, float* sums, float* partials, float* dgamma,
+               float* dbeta, int n, int hw, int c, int groups, float eps, int silu, int x_f16,
+               pti_stream_t s);
 /* Fused form used by the engine: the data-gradient conv computes dy = dA * act'(GN(gx)) in its epilogue and
- * accumulates gsums[n][c] = {sum dy, sum dy*xhat} (gx = the GroupNorm input, same shape as the conv output;
- * d->groups / d->eps describe that GroupNorm; d is a plain stride-1 / zero-insert launch, w_packed the
- * transposed+flipped pack).  pti_gn_bwd_apply then finishes dx = rstd*(gamma*dy - c1 - xhat*c2) [+ dres].    */
+ * stores, per pixel tile, the partial row gpartials[n][tile][c] = {sum dy, sum dy*xhat} (gx = the GroupNorm input,
+ * same shape as the conv output; d->groups / d->eps describe that GroupNorm; d is a plain stride-1 / zero-insert
+ * launch, w_packed the transposed+flipped pack; gpartials holds n * pti_conv_gnbwd_tiles(d) * cout * 2 floats).
+ * pti_gn_sums_finalize(gpartials, sums, n, tiles, 2*cout) adds the tile rows up into sums[n][c][2];
+ * pti_gn_bwd_apply then finishes dx = rstd*(gamma*dy - c1 - xhat*c2) [+ dres] and dgamma / dbeta +=.           */
+int pti_conv_gnbwd_tiles(const pti_conv_desc* d);
 int pti_conv2d_mfma_gnbwd(const void* dy_in, const void* w_packed, const void* gx, const int64_t* gstats,
-                          const float* ggamma, const float* gbeta, void* dy_out, float* gsums,
+                          const float* ggamma, const float* gbeta, void* dy_out, float* gpartials,
                           const pti_conv_desc* d, int silu, pti_stream_t s);
+int pti_gn_sums_finalize(const float* partials, float* sums, int n, int tiles, int row_len,
+                         pti_stream_t s);
 int pti_gn_bwd_apply(const void* x, const void* dy, const void* dres, void* dx, const int64_t* stats,
                      const float* gamma, const float* beta, const float* sums, float* dgamma,
                      float* dbeta, int n, int hw, int c, int groups, float eps, int x_f16,
@@ -193,23 +204,37 @@ int pti_latent_head_fwd(const float* h, const float* eps, const float* wm, const
                         pti_stream_t s);
 int pti_post_quant(const float* z_nchw, const float* wp, const float* bp, float* zq_nhwc, int b,
                    int hw, int l, pti_stream_t s);
-/* backward of pti_post_quant: dz (NCHW, may be NULL), gwp/gbp += (atomics).                      */
+/* backward of pti_post_quant: dz (NCHW, may be NULL), gwp/gbp +=.  workspace: float scratch of
+ * PTI_POST_QUANT_BWD_WS_FLOATS(l) elements (per-workgroup partials, added up in a fixed order by a second
+ * launch: no float atomics for l == 4, see pti_latent_head_bwd).                                 */
+#define PTI_POST_QUANT_BWD_MAX_BLOCKS 256
+#define PTI_POST_QUANT_BWD_WS_FLOATS(l) (PTI_POST_QUANT_BWD_MAX_BLOCKS * ((l) * (l) + (l)))
 int pti_post_quant_bwd(const float* dzq_nhwc, const float* z_nchw, const float* wp, float* dz_nchw,
-                       float* gwp, float* gbp, int b, int hw, int l, pti_stream_t s);
+                       float* gwp, float* gbp, float* workspace, int b, int hw, int l,
+                       pti_stream_t s);
+/* backward of pti_latent_head_fwd: dh, and g* += the six 1x1-conv parameter gradients.  workspace: float scratch
+ * of PTI_LATENT_BWD_WS_FLOATS(l) elements -- every workgroup stores its partial gradients there and a second
+ * launch adds them up in a fixed order (no float atomics: bitwise reproducible for l == 4, the reference's
+ * latent width; other widths still fold per-element partials with LDS atomics inside a workgroup).            */
+#define PTI_LATENT_BWD_MAX_BLOCKS 512
+#define PTI_LATENT_BWD_WS_FLOATS(l) (PTI_LATENT_BWD_MAX_BLOCKS * 3 * ((l) * (l) + (l)))
 int pti_latent_head_bwd(const float* h, const float* eps, const float* wm, const float* bm,
                         const float* wl, const float* bl, const float* wp, const float* bp,
                         const float* dzq, const float* dmu, const float* dsigma, float* dh,
                         float* gwm, float* gbm, float* gwl, float* gbl, float* gwp, float* gbp,
-                        int b, int hw, int l, pti_stream_t s);
+                        float* workspace, int b, int hw, int l, pti_stream_t s);
 
 /* ---- loss step (reference src/pti_ldm_vae/models/losses.py:25-30,62-66; train_vae.py:393-394) */
 /* out2[0] += mean recon loss (L1, or L2 when l2), out2[1] += mean_b KL; d_* receive the gradient
  * of recon + kl_weight*kl (NULL to skip).  third_mode 0: third used as log-variance (the
- * reference call site); 1: third is sigma, input_is_logvar=False semantics.                    */
+ * reference call site); 1: third is sigma, input_is_logvar=False semantics.  workspace: float scratch of
+ * PTI_VAE_LOSS_WS_FLOATS elements (per-workgroup partials, added up in a fixed order by a second launch).   */
+#define PTI_VAE_LOSS_MAX_BLOCKS 1024
+#define PTI_VAE_LOSS_WS_FLOATS (2 * PTI_VAE_LOSS_MAX_BLOCKS)
 int pti_vae_loss(const float* recon, const float* images, int64_t npix, const float* mu,
                  const float* third, int64_t nlat, int batch, float* out2, float* d_recon,
-                 float* d_mu, float* d_third, int l2, int third_mode, float kl_weight,
-                 pti_stream_t s);
+                 float* d_mu, float* d_third, float* workspace, int l2, int third_mode,
+                 float kl_weight, pti_stream_t s);
 
 /* ---- optimiser (torch.optim.Adam defaults, train_vae.py:301) on a flat fp32 arena ----------- */
 int pti_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,

@@ -54,7 +54,10 @@ SIGNATURES = {
     "pti_conv_wgrad_mfma": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I, C.POINTER(ConvDesc), _P]),
     "pti_conv_wgrad_mfma_partials": (_I, [_P, _P, _P, _P, _P, _P, _I64, C.POINTER(ConvDesc), C.POINTER(_I), _P]),
     "pti_conv_wgrad_reduce": (_I, [_P, _I, _P, _P, _I, C.POINTER(ConvDesc), _P]),
-    "pti_gn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _P]),
+    "pti_gn_bwd_blocks": (_I, [_I, _I, _I]),
+    "pti_gn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _P]),
+    "pti_conv_gnbwd_tiles": (_I, [C.POINTER(ConvDesc)]),
+    "pti_gn_sums_finalize": (_I, [_P, _P, _I, _I, _I, _P]),
     "pti_conv2d_mfma_gnbwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(ConvDesc), _I, _P]),
     "pti_gn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
     "pti_pool2x2_sum": (_I, [_P, _P, _I, _I, _I, _I, _P]),
@@ -62,9 +65,9 @@ SIGNATURES = {
     "pti_attention_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "pti_latent_head_fwd": (_I, [_P] * 12 + [_I, _I, _I, _P]),
     "pti_post_quant": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
-    "pti_post_quant_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
-    "pti_latent_head_bwd": (_I, [_P] * 18 + [_I, _I, _I, _P]),
-    "pti_vae_loss": (_I, [_P, _P, _I64, _P, _P, _I64, _I, _P, _P, _P, _P, _I, _I, _F, _P]),
+    "pti_post_quant_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "pti_latent_head_bwd": (_I, [_P] * 19 + [_I, _I, _I, _P]),
+    "pti_vae_loss": (_I, [_P, _P, _I64, _P, _P, _I64, _I, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
     "pti_adam_step": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I, _F, _P]),
     "pti_preprocess_batch": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "pti_cast_nchw_f32_to_nhwc_bf16": (_I, [_P, _P, _I, _I, _I, _P]),

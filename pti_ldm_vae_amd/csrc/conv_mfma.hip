@@ -77,7 +77,8 @@ struct ConvArgs {
   int g_groups;
   float g_inv_cnt, g_eps;
   const stat_t* g_stats; const float* g_gamma; const float* g_beta;
-  float* g_sums;
+  float* g_sums;          // PARTIAL sums [N][g_T][Cout][2] (one slot per pixel tile, plain stores; pti_gn_sums_finalize adds them up)
+  int g_T;                // pixel tiles per sample
   // optional side output (v2 kernel, PTI_CONV_S1 with a prologue): the activated input act(GN(x)) as bf16 NHWC,
   // written by the cout-tile-0 workgroups from their staging registers, for the weight-gradient pass to reuse
   bf16* act_out;
@@ -671,7 +672,7 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
   if (a.gn_mode) {
     // (B') data gradient + GroupNorm backward reduction: etile holds the GN input gx
     const int gcpg = a.Cout / a.g_groups;
-    float* gsm = reinterpret_cast<float*>(smem + C::STAT_OFF);   // [CT][2], zeroed before the main loop
+    float* gsm = reinterpret_cast<float*>(smem + C::STAT_OFF);   // [WM][CT][2]: one slot per (pixel group, channel, sum)
     float L[32];   // [q][r][{sum dy, sum dy*xhat}] of this lane
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -722,8 +723,10 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
         L[8 * q + 2 * r + 1] = l2[r];
       }
     }
-    fold32<32>(L, j);   // lane j now holds the half-wave total of value j = 8q + 2r + s, i.e. gsm[(col0 + 8q + r) * 2 + s]
-    atomicAdd(&gsm[col0 * 2 + 16 * (j >> 3) + (j & 7)], L[0]);
+    fold32<32>(L, j);   // lane j now holds the half-wave total of value j = 8q + 2r + s, i.e. channel col0 + 8q + r, sum s
+    // plain store into this wave's own slot (the waves of one channel range differ in wm): no atomics, so the
+    // workgroup's partial -- summed over wm in a fixed order below -- is bitwise reproducible
+    gsm[wm * 2 * CT + col0 * 2 + 16 * (j >> 3) + (j & 7)] = L[0];
   } else {
   // (B) registers -> (+bias, +residual) -> bf16 -> LDS tile; statistics accumulate in-lane over the 4 fragments
 #pragma unroll
@@ -829,8 +832,14 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
                                   (u32x4*)(a.y + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.Cout + ct * CT + epc * 8));
   }
   if (a.gn_mode) {
-    if (tid < 2 * CT)
-      atomicAdd(&a.g_sums[((size_t)n * a.Cout + ct * CT) * 2 + tid], reinterpret_cast<float*>(smem + C::STAT_OFF)[tid]);
+    if (tid < 2 * CT) {
+      const float* gsm = reinterpret_cast<const float*>(smem + C::STAT_OFF);
+      float v = gsm[tid];
+#pragma unroll
+      for (int m = 1; m < C::WM; ++m) v += gsm[m * 2 * CT + tid];
+      // partial of this pixel tile: [n][tile][channel][sum], one coalesced plain store per workgroup
+      a.g_sums[(((size_t)n * a.g_T + tile_y * a.tiles_x + tile_x) * a.Cout + ct * CT) * 2 + tid] = v;
+    }
   } else if (do_stats) {
     const stat_t* sstat = reinterpret_cast<const stat_t*>(smem + C::STAT_OFF);
     const int g0 = (ct * CT) / ocpg, ng = CT / ocpg;   // one wave-instruction of global atomics per workgroup
@@ -844,6 +853,7 @@ int launch2_cfg(ConvArgs a, hipStream_t st) {
   using C = Cfg2<KS, CK, CT, PXF>;
   a.tiles_x = cdiv(a.Wo, C::TW2);
   a.tiles_y = cdiv(a.Ho, C::TH2);
+  a.g_T = a.tiles_x * a.tiles_y;
   dim3 grid(a.N * a.tiles_x * a.tiles_y, a.Cout / CT);
   if constexpr (KS == 3) {   // the activated-input side output is a separate instantiation (3x3 only)
     if (a.act_out) {
@@ -1070,7 +1080,7 @@ static int conv2d_mfma_impl(const void* x, const void* w_packed, const float* bi
   a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Ho = d->ho; a.Wo = d->wo; a.Cout = d->cout;
   a.mode = d->mode; a.prologue = d->prologue; a.groups = d->groups; a.out_groups = d->out_groups;
   a.gn_mode = 0; a.g_groups = 0; a.g_inv_cnt = 0.f; a.g_eps = 0.f;
-  a.g_stats = nullptr; a.g_gamma = a.g_beta = nullptr; a.g_sums = nullptr;
+  a.g_stats = nullptr; a.g_gamma = a.g_beta = nullptr; a.g_sums = nullptr; a.g_T = 0;
   a.act_out = (bf16*)act_out;
   a.in_f16 = d->in_f16; a.res_f16 = d->res_f16; a.out_f16 = d->out_f16;
   a.pool2 = d->pool2x2_out;
@@ -1110,6 +1120,15 @@ extern "C" int pti_conv2d_mfma_saveact(const void* x, const void* w_packed, cons
                                        int64_t* out_stats, void* act_out, const pti_conv_desc* d, pti_stream_t s) {
   if (!act_out) PTI_FAIL(PTI_EINVAL, "conv2d_mfma_saveact: null act_out");
   return conv2d_mfma_impl(x, w_packed, bias, in_stats, gamma, beta, residual, y, out_stats, d, nullptr, act_out, s);
+}
+
+// pixel tiles per sample of the launch pti_conv2d_mfma_gnbwd(d) makes: the partial-sum buffer holds
+// n * cout * 2 * tiles floats
+extern "C" int pti_conv_gnbwd_tiles(const pti_conv_desc* d) {
+  if (!d || d->cout % 32 || d->ho <= 0 || d->wo <= 0) return 0;
+  const int ct = pick_cout_tile(d->cout);
+  const int th = ct == 128 ? 8 : (ct == 64 ? 8 : 16);   // Cfg2::TH2 = 2 * PXF * WM with PXF = 4 (ct 128) or 2
+  return cdiv(d->ho, th) * cdiv(d->wo, 16);
 }
 
 extern "C" int pti_conv2d_mfma_gnbwd(const void* dy_in, const void* w_packed, const void* gx, const int64_t* gstats,

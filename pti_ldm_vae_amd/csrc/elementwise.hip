@@ -79,11 +79,19 @@ __global__ __launch_bounds__(256) void post_quant_kernel(const float* z, const f
   }
 }
 
-// backward of post_quant_kernel: dz[b][j][p] = sum_i wp[i][j] dzq[b][p][i]; gwp[i][j] += dzq_i z_j; gbp += dzq
+// backward of post_quant_kernel: dz[b][j][p] = sum_i wp[i][j] dzq[b][p][i]; block partials of gwp[i][j] = sum dzq_i z_j
+// and gbp = sum dzq go to part[block][L*L+L] (added up in a fixed order by block_partials_finalize_kernel).
+// LT > 0: L == LT at compile time, the partials live in registers and fold with shuffles (no atomics at all).
+template <int LT>
 __global__ __launch_bounds__(256) void post_quant_bwd_kernel(const float* dzq, const float* z, const float* wp, float* dz,
-                                                             float* gwp, float* gbp, int B, int HW, int L) {
-  extern __shared__ float sm[];  // L*L + L
-  for (int i = threadIdx.x; i < L * L + L; i += 256) sm[i] = 0.f;
+                                                             float* part, int B, int HW, int Lrt) {
+  extern __shared__ float sm[];  // LT > 0: [4 waves][L*L + L], else L*L + L
+  const int L = LT > 0 ? LT : Lrt, LL = L * L + L;
+  constexpr int NACC = LT > 0 ? LT * LT + LT : 1;
+  float racc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) racc[i] = 0.f;
+  for (int i = threadIdx.x; i < LL; i += 256) sm[i] = 0.f;
   __syncthreads();
   const long long total = (long long)B * HW;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
@@ -100,13 +108,28 @@ __global__ __launch_bounds__(256) void post_quant_bwd_kernel(const float* dzq, c
       if (dz) dz[((size_t)b * L + j) * HW + p] = v;
     }
     for (int i = 0; i < L; ++i) {
-      atomicAdd(&sm[L * L + i], g[i]);
-      for (int j = 0; j < L; ++j) atomicAdd(&sm[i * L + j], g[i] * zz[j]);
+      if constexpr (LT > 0) {
+        racc[L * L + i] += g[i];
+        for (int j = 0; j < L; ++j) racc[i * L + j] += g[i] * zz[j];
+      } else {
+        atomicAdd(&sm[L * L + i], g[i]);
+        for (int j = 0; j < L; ++j) atomicAdd(&sm[i * L + j], g[i] * zz[j]);
+      }
+    }
+  }
+  if constexpr (LT > 0) {
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) {
+      const float v = wave_sum(racc[i]);
+      if ((threadIdx.x & 63) == 0) sm[(threadIdx.x >> 6) * NACC + i] = v;
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < L * L; i += 256) atomicAdd(&gwp[i], sm[i]);
-  for (int i = threadIdx.x; i < L; i += 256) atomicAdd(&gbp[i], sm[L * L + i]);
+  for (int i = threadIdx.x; i < LL; i += 256) {
+    float v = sm[i];
+    if constexpr (LT > 0) v = (sm[i] + sm[NACC + i]) + (sm[2 * NACC + i] + sm[3 * NACC + i]);
+    part[(size_t)blockIdx.x * LL + i] = v;
+  }
 }
 
 struct LatBwdArgs {
@@ -116,16 +139,36 @@ struct LatBwdArgs {
   const float* dmu;      // [B,L,HW] NCHW fp32 or null   (external gradient on mu)
   const float* dsigma;   // [B,L,HW] NCHW fp32 or null   (external gradient on sigma)
   float* dh;             // [B,HW,L]
-  float* gwm; float* gbm; float* gwl; float* gbl; float* gwp; float* gbp;  // accumulated (atomics)
+  float* gwm; float* gbm; float* gwl; float* gbl; float* gwp; float* gbp;  // accumulated by the finalising launch
   int B, HW, L;
+  float* part;           // [blocks][3*(L*L+L)] block partials of the six parameter gradients
 };
+
+// Fixed-order second stage of the small reductions (latent-head parameter gradients, loss terms): workgroup i adds
+// value i of every block partial row -- lanes stride the rows, then a fixed shuffle tree -- and ONE lane accumulates
+// it into its destination.  No float atomics: the result does not depend on the order the first stage's blocks ran.
+struct FinSegs { float* dst[6]; int len[6]; int nseg; };
+__global__ __launch_bounds__(64) void block_partials_finalize_kernel(const float* __restrict__ part, int nb, int stride,
+                                                                     FinSegs sg) {
+  const int i = blockIdx.x, lane = threadIdx.x;
+  float v = 0.f;
+  for (int b = lane; b < nb; b += 64) v += part[(size_t)b * stride + i];
+  v = wave_sum(v);
+  if (lane == 0) {
+    int r = i;
+    for (int k = 0; k < sg.nseg; ++k) {
+      if (r < sg.len[k]) { sg.dst[k][r] += v; return; }
+      r -= sg.len[k];
+    }
+  }
+}
 
 // LT > 0: L == LT known at compile time -> the 3*(L*L+L) weight/bias gradient partials live in registers over the
 // thread's elements and are reduced once per wave with shuffles (the generic form does one LDS atomic per partial
 // and element: 256 threads x 60 atomics on the same 60 addresses per iteration = 93 us for a 131k-element map).
 template <int LT>
 __global__ __launch_bounds__(256) void latent_bwd_kernel(LatBwdArgs a) {
-  extern __shared__ float sm[];  // 3*(L*L+L)
+  extern __shared__ float sm[];  // LT > 0: [4 waves][3*(L*L+L)], else 3*(L*L+L)
   const int L = LT > 0 ? LT : a.L, LL = L * L + L;
   constexpr int NACC = LT > 0 ? 3 * (LT * LT + LT) : 1;
   float racc[NACC];
@@ -190,34 +233,31 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(LatBwdArgs a) {
       a.dh[e * L + j] = v;
     }
   }
-  if constexpr (LT > 0) {   // sm is laid out exactly like racc: [wm | bm | wl | bl | wp | bp]
+  if constexpr (LT > 0) {   // a wave's LDS row is laid out exactly like racc: [wm | bm | wl | bl | wp | bp]
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < NACC; ++i) {
       const float v = wave_sum(racc[i]);
-      if ((threadIdx.x & 63) == 0) atomicAdd(&sm[i], v);
+      if ((threadIdx.x & 63) == 0) sm[(threadIdx.x >> 6) * NACC + i] = v;
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < L * L; i += 256) {
-    atomicAdd(&a.gwm[i], s_wm[i]);
-    atomicAdd(&a.gwl[i], s_wl[i]);
-    atomicAdd(&a.gwp[i], s_wp[i]);
-  }
-  for (int i = threadIdx.x; i < L; i += 256) {
-    atomicAdd(&a.gbm[i], s_bm[i]);
-    atomicAdd(&a.gbl[i], s_bl[i]);
-    atomicAdd(&a.gbp[i], s_bp[i]);
+  // block partial row (plain stores); block_partials_finalize_kernel adds the rows up in a fixed order
+  for (int i = threadIdx.x; i < 3 * LL; i += 256) {
+    float v = sm[i];
+    if constexpr (LT > 0) v = (sm[i] + sm[NACC + i]) + (sm[2 * NACC + i] + sm[3 * NACC + i]);
+    a.part[(size_t)blockIdx.x * 3 * LL + i] = v;
   }
 }
 
 // ---- loss -------------------------------------------------------------------------------------
-// out[0] += sum |r-x| or (r-x)^2 ; out[1] += sum_kl ; gradient seeds written scaled so that
+// part[block] = {sum |r-x| or (r-x)^2, sum_kl} of the block's elements (out2 += their fixed-order total); gradient seeds written scaled so that
 // d(total)/d(.) with total = mean_recon + kl_weight * mean_b(kl)  (losses.py:62-66 with the other
 // weights zero).  third_mode 0: third is used as log-variance (the reference call, train_vae.py:394);
 // 1: third is sigma with input_is_logvar=False (losses.py:25-26).
 __global__ __launch_bounds__(256) void vae_loss_kernel(const float* __restrict__ recon, const float* __restrict__ img,
                                                        long long npix, const float* __restrict__ mu,
-                                                       const float* __restrict__ third, long long nlat, float* out,
+                                                       const float* __restrict__ third, long long nlat, float* part,
                                                        float* d_recon, float* d_mu, float* d_third, int l2,
                                                        int third_mode, float kl_weight, float inv_npix, float inv_b) {
   float sr = 0.f, sk = 0.f;
@@ -250,9 +290,9 @@ __global__ __launch_bounds__(256) void vae_loss_kernel(const float* __restrict__
   const int wave = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) { red[wave] = sr; red[4 + wave] = sk; }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    atomicAdd(&out[0], (red[0] + red[1] + red[2] + red[3]) * inv_npix);
-    atomicAdd(&out[1], (red[4] + red[5] + red[6] + red[7]) * inv_b);
+  if (threadIdx.x == 0) {   // block partial; block_partials_finalize_kernel adds the blocks up in a fixed order
+    part[2 * blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) * inv_npix;
+    part[2 * blockIdx.x + 1] = ((red[4] + red[5]) + (red[6] + red[7])) * inv_b;
   }
 }
 
@@ -324,44 +364,66 @@ extern "C" int pti_post_quant(const float* z_nchw, const float* wp, const float*
 }
 
 extern "C" int pti_post_quant_bwd(const float* dzq_nhwc, const float* z_nchw, const float* wp, float* dz_nchw,
-                                  float* gwp, float* gbp, int b, int hw, int l, pti_stream_t s) {
-  if (!dzq_nhwc || !z_nchw || !wp || !gwp || !gbp || l <= 0 || l > MAXL) PTI_FAIL(PTI_EINVAL, "post_quant_bwd: bad args");
-  hipLaunchKernelGGL(post_quant_bwd_kernel, dim3(nblocks((long long)b * hw, 256)), dim3(256), (l * l + l) * sizeof(float),
-                     (hipStream_t)s, dzq_nhwc, z_nchw, wp, dz_nchw, gwp, gbp, b, hw, l);
+                                  float* gwp, float* gbp, float* workspace, int b, int hw, int l, pti_stream_t s) {
+  if (!dzq_nhwc || !z_nchw || !wp || !gwp || !gbp || !workspace || l <= 0 || l > MAXL) PTI_FAIL(PTI_EINVAL, "post_quant_bwd: bad args");
+  const unsigned nb = nblocks((long long)b * hw, PTI_POST_QUANT_BWD_MAX_BLOCKS);
+  const int ll = l * l + l;
+  if (l == 4)
+    hipLaunchKernelGGL(post_quant_bwd_kernel<4>, dim3(nb), dim3(256), 4 * ll * sizeof(float), (hipStream_t)s, dzq_nhwc,
+                       z_nchw, wp, dz_nchw, workspace, b, hw, l);
+  else   // other latent widths fold per-element partials with LDS float atomics inside a workgroup
+    hipLaunchKernelGGL(post_quant_bwd_kernel<0>, dim3(nb), dim3(256), ll * sizeof(float), (hipStream_t)s, dzq_nhwc, z_nchw,
+                       wp, dz_nchw, workspace, b, hw, l);
   PTI_CHECK_LAUNCH("post_quant_bwd");
+  FinSegs sg{{gwp, gbp}, {l * l, l}, 2};
+  hipLaunchKernelGGL(block_partials_finalize_kernel, dim3(ll), dim3(64), 0, (hipStream_t)s, workspace, (int)nb, ll, sg);
+  PTI_CHECK_LAUNCH("post_quant_bwd_finalize");
   return PTI_OK;
 }
 
 extern "C" int pti_latent_head_bwd(const float* h, const float* eps, const float* wm, const float* bm,
                                    const float* wl, const float* bl, const float* wp, const float* bp,
                                    const float* dzq, const float* dmu, const float* dsigma, float* dh, float* gwm,
-                                   float* gbm, float* gwl, float* gbl, float* gwp, float* gbp, int b, int hw, int l,
-                                   pti_stream_t s) {
-  if (!h || !wm || !bm || !wl || !bl || !wp || !bp || !dh || !gwm || !gbm || !gwl || !gbl || !gwp || !gbp)
+                                   float* gbm, float* gwl, float* gbl, float* gwp, float* gbp, float* workspace,
+                                   int b, int hw, int l, pti_stream_t s) {
+  if (!h || !wm || !bm || !wl || !bl || !wp || !bp || !dh || !gwm || !gbm || !gwl || !gbl || !gwp || !gbp || !workspace)
     PTI_FAIL(PTI_EINVAL, "latent_head_bwd: null pointer");
   if (l <= 0 || l > MAXL) PTI_FAIL(PTI_EUNSUPPORTED, "latent_head_bwd: latent channels %d", l);
-  LatBwdArgs a{h, eps, wm, bm, wl, bl, wp, bp, dzq, dmu, dsigma, dh, gwm, gbm, gwl, gbl, gwp, gbp, b, hw, l};
+  LatBwdArgs a{h, eps, wm, bm, wl, bl, wp, bp, dzq, dmu, dsigma, dh, gwm, gbm, gwl, gbl, gwp, gbp, b, hw, l, workspace};
+  const int ll = l * l + l;
+  long long nb;
   if (l == 4)
   {   // ~4 elements per thread: the 60 wave reductions at the end are amortised
-    long long nb = ((long long)b * hw + 1023) / 1024;
-    nb = nb < 1 ? 1 : (nb > 512 ? 512 : nb);
-    hipLaunchKernelGGL(latent_bwd_kernel<4>, dim3((unsigned)nb), dim3(256), 3 * (l * l + l) * sizeof(float), (hipStream_t)s, a);
+    nb = ((long long)b * hw + 1023) / 1024;
+    nb = nb < 1 ? 1 : (nb > PTI_LATENT_BWD_MAX_BLOCKS ? PTI_LATENT_BWD_MAX_BLOCKS : nb);
+    hipLaunchKernelGGL(latent_bwd_kernel<4>, dim3((unsigned)nb), dim3(256), 4 * 3 * ll * sizeof(float), (hipStream_t)s, a);
   }
-  else
-    hipLaunchKernelGGL(latent_bwd_kernel<0>, dim3(nblocks((long long)b * hw, 256)), dim3(256), 3 * (l * l + l) * sizeof(float),
-                       (hipStream_t)s, a);
+  else {
+    // other latent widths: the per-element partials go through LDS float atomics inside a block (rounding order
+    // may vary run to run there); the cross-block stage is the same fixed-order one
+    nb = nblocks((long long)b * hw, 256);
+    hipLaunchKernelGGL(latent_bwd_kernel<0>, dim3((unsigned)nb), dim3(256), 3 * ll * sizeof(float), (hipStream_t)s, a);
+  }
   PTI_CHECK_LAUNCH("latent_head_bwd");
+  FinSegs sg{{gwm, gbm, gwl, gbl, gwp, gbp}, {l * l, l, l * l, l, l * l, l}, 6};
+  hipLaunchKernelGGL(block_partials_finalize_kernel, dim3(3 * ll), dim3(64), 0, (hipStream_t)s, workspace, (int)nb, 3 * ll, sg);
+  PTI_CHECK_LAUNCH("latent_head_bwd_finalize");
   return PTI_OK;
 }
 
 extern "C" int pti_vae_loss(const float* recon, const float* images, int64_t npix, const float* mu,
                             const float* third, int64_t nlat, int batch, float* out2, float* d_recon, float* d_mu,
-                            float* d_third, int l2, int third_mode, float kl_weight, pti_stream_t s) {
-  if (!recon || !images || !mu || !third || !out2 || npix <= 0 || nlat <= 0 || batch <= 0) PTI_FAIL(PTI_EINVAL, "vae_loss: bad args");
-  hipLaunchKernelGGL(vae_loss_kernel, dim3(nblocks(npix, 1024)), dim3(256), 0, (hipStream_t)s, recon, images,
-                     (long long)npix, mu, third, (long long)nlat, out2, d_recon, d_mu, d_third, l2, third_mode, kl_weight,
+                            float* d_third, float* workspace, int l2, int third_mode, float kl_weight, pti_stream_t s) {
+  if (!recon || !images || !mu || !third || !out2 || !workspace || npix <= 0 || nlat <= 0 || batch <= 0)
+    PTI_FAIL(PTI_EINVAL, "vae_loss: bad args");
+  const unsigned nb = nblocks(npix, PTI_VAE_LOSS_MAX_BLOCKS);
+  hipLaunchKernelGGL(vae_loss_kernel, dim3(nb), dim3(256), 0, (hipStream_t)s, recon, images,
+                     (long long)npix, mu, third, (long long)nlat, workspace, d_recon, d_mu, d_third, l2, third_mode, kl_weight,
                      1.0f / (float)npix, 1.0f / (float)batch);
   PTI_CHECK_LAUNCH("vae_loss");
+  FinSegs sg{{out2}, {2}, 1};
+  hipLaunchKernelGGL(block_partials_finalize_kernel, dim3(2), dim3(64), 0, (hipStream_t)s, workspace, (int)nb, 2, sg);
+  PTI_CHECK_LAUNCH("vae_loss_finalize");
   return PTI_OK;
 }
 

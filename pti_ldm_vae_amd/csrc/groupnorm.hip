@@ -122,13 +122,15 @@ struct GnbArgs {
   int HW, C, G, silu, ppb;
   float eps, inv_cnt;
   int x_f16;   // x (a forward activation) is stored fp16; da / dres / dx are gradients: always bf16
+  int N;
+  float* part;   // gn_bwd_reduce: per-block partial sums [N][blocks per sample][C][2]
 };
 
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnbArgs a) {
-  extern __shared__ float sm[];  // [C][2]
+  extern __shared__ float sm[];  // [4 waves][C][2]: every wave owns a slot, no atomics (bitwise reproducible)
   const int n = blockIdx.y, tid = threadIdx.x;
   const int NC = a.C / 8, ppi = 256 / NC, lc = tid % NC, lp = tid / NC;
-  for (int i = tid; i < 2 * a.C; i += 256) sm[i] = 0.f;
+  for (int i = tid; i < 8 * a.C; i += 256) sm[i] = 0.f;
   __syncthreads();
   const int cpg = a.C / a.G;
   float sc[8], sh[8], mu[8], rs[8];
@@ -182,18 +184,52 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnbArgs a) {
       v1 += __shfl_xor(v1, o, 64);
       v2 += __shfl_xor(v2, o, 64);
     }
-    if ((tid & 63) < NC || NC > 64) {
-      atomicAdd(&sm[(lc * 8 + j) * 2], v1);
-      atomicAdd(&sm[(lc * 8 + j) * 2 + 1], v2);
+    // NC <= 64: after the fold lanes 0..NC-1 of each wave hold the wave's totals for their channels
+    if ((tid & 63) < NC) {
+      float* slot = sm + (tid >> 6) * 2 * a.C;
+      slot[(lc * 8 + j) * 2] = v1;
+      slot[(lc * 8 + j) * 2 + 1] = v2;
     }
   }
   __syncthreads();
-  for (int i = tid; i < a.C; i += 256) {
-    const float v1 = sm[2 * i], v2 = sm[2 * i + 1];
-    atomicAdd(&a.sums[((size_t)n * a.C + i) * 2], v1);
-    atomicAdd(&a.sums[((size_t)n * a.C + i) * 2 + 1], v2);
-    // dgamma / dbeta are folded from sums[n][c] by block 0 of each sample in the apply kernel: adding them
-    // here would make every block of the launch hammer the same 2*C addresses
+  // block partial -> part[n][block][c][s] (plain stores; pti_gn_sums_finalize adds the blocks up in a fixed order;
+  // dgamma / dbeta are folded from the finished sums by one block of the apply kernel)
+  for (int i = tid; i < 2 * a.C; i += 256) {
+    const float v = (sm[i] + sm[2 * a.C + i]) + (sm[4 * a.C + i] + sm[6 * a.C + i]);
+    a.part[((size_t)n * gridDim.x + blockIdx.x) * 2 * a.C + i] = v;
+  }
+}
+
+// sums[n][i] = sum_t part[n][t][i] for i = (channel, {sum dy, sum dy*xhat}): the data-gradient convs and
+// gn_bwd_reduce write one partial row per pixel tile / block with plain stores, and this kernel adds the rows up in
+// a fixed order (wave w takes tiles w, w+16, ...; the 16 wave totals are folded as a fixed tree), so the totals do
+// not depend on the order workgroups ran in.  64 consecutive i per workgroup: every load is one 256-byte row piece.
+__global__ __launch_bounds__(1024) void gn_sums_finalize_kernel(const float* __restrict__ part, float* __restrict__ sums,
+                                                                int T, int R) {
+  __shared__ float red[16][64];
+  const int n = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  float v = 0.f;
+  if (i < R) {
+    const float* p = part + (size_t)n * T * R + i;
+    int t = w;
+    for (; t + 48 < T; t += 64) {   // four independent loads in flight
+      const float a0 = p[(size_t)t * R], a1 = p[(size_t)(t + 16) * R], a2 = p[(size_t)(t + 32) * R], a3 = p[(size_t)(t + 48) * R];
+      v += (a0 + a1) + (a2 + a3);
+    }
+    for (; t < T; t += 16) v += p[(size_t)t * R];
+  }
+  red[w][lane] = v;
+  __syncthreads();
+  if (w == 0 && i < R) {
+    float r[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) r[k] = red[k][lane];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1)
+#pragma unroll
+      for (int k = 0; k < o; ++k) r[k] += r[k + o];
+    sums[(size_t)n * R + i] = r[0];
   }
 }
 
@@ -244,10 +280,15 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnbArgs a) {
       c2[j] = t2 * a.inv_cnt;
     }
   }
-  if (blockIdx.x == 0) {  // per-sample contribution to the affine gradients: N adds per address in total
+  if (blockIdx.x == 0 && n == 0) {  // affine gradients: ONE block walks the samples in order (no atomics: reproducible)
     for (int i = tid; i < a.C; i += 256) {
-      if (a.dbeta) atomicAdd(&a.dbeta[i], a.sums[((size_t)n * a.C + i) * 2]);
-      if (a.dgamma) atomicAdd(&a.dgamma[i], a.sums[((size_t)n * a.C + i) * 2 + 1]);
+      float d1 = 0.f, d2 = 0.f;
+      for (int m = 0; m < a.N; ++m) {
+        d1 += a.sums[((size_t)m * a.C + i) * 2];
+        d2 += a.sums[((size_t)m * a.C + i) * 2 + 1];
+      }
+      if (a.dbeta) a.dbeta[i] += d1;
+      if (a.dgamma) a.dgamma[i] += d2;
     }
   }
   const int p0 = blockIdx.x * a.ppb, p1 = min(p0 + a.ppb, a.HW);
@@ -310,25 +351,41 @@ __global__ __launch_bounds__(256) void pool2x2_sum_kernel(const bf16* __restrict
 
 }  // namespace
 
-extern "C" int pti_gn_bwd(const void* x, const void* da, const void* dres, void* dx, const int64_t* stats,
-                          const float* gamma, const float* beta, float* sums, float* dgamma, float* dbeta, int n,
-                          int hw, int c, int groups, float eps, int silu, int x_f16, pti_stream_t s) {
-  if (!x || !da || !dx || !stats || !gamma || !beta || !sums) PTI_FAIL(PTI_EINVAL, "gn_bwd: null pointer");
-  if (c < 8 || c > 2048 || (c & (c - 1)) || groups <= 0 || c % groups) PTI_FAIL(PTI_EUNSUPPORTED, "gn_bwd: c=%d groups=%d", c, groups);
-  GnbArgs a;
-  a.x = (const bf16*)x; a.da = (const bf16*)da; a.dres = (const bf16*)dres; a.dx = (bf16*)dx;
-  a.stats = (const stat_t*)stats; a.gamma = gamma; a.beta = beta; a.sums = sums; a.dgamma = dgamma; a.dbeta = dbeta;
-  a.HW = hw; a.C = c; a.G = groups; a.silu = silu; a.eps = eps; a.x_f16 = x_f16;
-  a.inv_cnt = 1.0f / ((float)(c / groups) * (float)hw);
+static int gn_bwd_grid(int n, int hw, int c, int* ppb_out) {
   const int ppi = 256 / (c / 8);
   int bps = cdiv(2048, n);
   int ppb = cdiv(hw, bps);
   if (ppb < 16 * ppi) ppb = 16 * ppi;
   ppb = cdiv(ppb, ppi) * ppi;
-  bps = cdiv(hw, ppb);
+  if (ppb_out) *ppb_out = ppb;
+  return cdiv(hw, ppb);
+}
+
+// blocks per sample of the reduction launch: `partials` of pti_gn_bwd holds n * c * 2 * blocks floats
+extern "C" int pti_gn_bwd_blocks(int n, int hw, int c) {
+  if (n <= 0 || hw <= 0 || c < 8 || (c & (c - 1)) || c > 512) return 0;
+  return gn_bwd_grid(n, hw, c, nullptr);
+}
+
+extern "C" int pti_gn_bwd(const void* x, const void* da, const void* dres, void* dx, const int64_t* stats,
+                          const float* gamma, const float* beta, float* sums, float* partials, float* dgamma,
+                          float* dbeta, int n, int hw, int c, int groups, float eps, int silu, int x_f16, pti_stream_t s) {
+  if (!x || !da || !dx || !stats || !gamma || !beta || !sums || !partials) PTI_FAIL(PTI_EINVAL, "gn_bwd: null pointer");
+  if (c < 8 || c > 512 || (c & (c - 1)) || groups <= 0 || c % groups) PTI_FAIL(PTI_EUNSUPPORTED, "gn_bwd: c=%d groups=%d", c, groups);
+  GnbArgs a;
+  a.x = (const bf16*)x; a.da = (const bf16*)da; a.dres = (const bf16*)dres; a.dx = (bf16*)dx;
+  a.stats = (const stat_t*)stats; a.gamma = gamma; a.beta = beta; a.sums = sums; a.dgamma = dgamma; a.dbeta = dbeta;
+  a.HW = hw; a.C = c; a.G = groups; a.silu = silu; a.eps = eps; a.x_f16 = x_f16; a.N = n;
+  a.inv_cnt = 1.0f / ((float)(c / groups) * (float)hw);
+  int ppb;
+  const int bps = gn_bwd_grid(n, hw, c, &ppb);
   a.ppb = ppb;
-  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(bps, n), dim3(256), 2 * c * sizeof(float), (hipStream_t)s, a);
+  a.part = partials;
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(bps, n), dim3(256), 8 * c * sizeof(float), (hipStream_t)s, a);
   PTI_CHECK_LAUNCH("gn_bwd_reduce");
+  hipLaunchKernelGGL(gn_sums_finalize_kernel, dim3(cdiv(2 * c, 64), n), dim3(1024), 0, (hipStream_t)s, partials, sums,
+                     bps, 2 * c);
+  PTI_CHECK_LAUNCH("gn_sums_finalize");
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(bps, n), dim3(256), 0, (hipStream_t)s, a);
   PTI_CHECK_LAUNCH("gn_bwd_apply");
   return PTI_OK;
@@ -344,7 +401,7 @@ extern "C" int pti_gn_bwd_apply(const void* x, const void* dy, const void* dres,
   GnbArgs a;
   a.x = (const bf16*)x; a.da = (const bf16*)dy; a.dres = (const bf16*)dres; a.dx = (bf16*)dx;
   a.stats = (const stat_t*)stats; a.gamma = gamma; a.beta = beta; a.sums = const_cast<float*>(sums); a.dgamma = dgamma; a.dbeta = dbeta;
-  a.HW = hw; a.C = c; a.G = groups; a.silu = 0; a.eps = eps; a.x_f16 = x_f16;
+  a.HW = hw; a.C = c; a.G = groups; a.silu = 0; a.eps = eps; a.x_f16 = x_f16; a.N = n;
   a.inv_cnt = 1.0f / ((float)(c / groups) * (float)hw);
   const int ppi = 256 / (c / 8);
   int bps = cdiv(2048, n);
@@ -355,6 +412,14 @@ extern "C" int pti_gn_bwd_apply(const void* x, const void* dy, const void* dres,
   a.ppb = ppb;
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(bps, n), dim3(256), 0, (hipStream_t)s, a);
   PTI_CHECK_LAUNCH("gn_bwd_apply");
+  return PTI_OK;
+}
+
+extern "C" int pti_gn_sums_finalize(const float* partials, float* sums, int n, int tiles, int row_len, pti_stream_t s) {
+  if (!partials || !sums || n <= 0 || tiles <= 0 || row_len <= 0) PTI_FAIL(PTI_EINVAL, "gn_sums_finalize: bad args");
+  hipLaunchKernelGGL(gn_sums_finalize_kernel, dim3(cdiv(row_len, 64), n), dim3(1024), 0, (hipStream_t)s, partials, sums,
+                     tiles, row_len);
+  PTI_CHECK_LAUNCH("gn_sums_finalize");
   return PTI_OK;
 }
 

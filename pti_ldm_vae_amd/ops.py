@@ -295,7 +295,7 @@ def _wgrad_kernel_name(ksize, mode, cin, cout, ntiles):
 
 
 def gn_bwd(x, da, dx, stats, gamma, beta, sums, dgamma, dbeta, *, groups, eps=1e-6, silu=True, dres=None):
-    """dx <- backward of act(GroupNorm(x)); ``sums`` is a ZEROED fp32 [n,c,2] scratch."""
+    """dx <- backward of act(GroupNorm(x)); ``sums`` is an fp32 [n,c,2] scratch (written; no zeroing needed)."""
     _chk(x, ACT16, "x", 4)
     _chk(da, BF16, "da", 4)
     _chk(dx, BF16, "dx", 4)
@@ -305,8 +305,12 @@ def gn_bwd(x, da, dx, stats, gamma, beta, sums, dgamma, dbeta, *, groups, eps=1e
     _chk_stats(stats, n * groups * 2, "stats")
     if sums.numel() != n * c * 2:
         raise ValueError("gn_bwd: scratch sizes")
+    blocks = L.lib().pti_gn_bwd_blocks(n, h * w, c)
+    if blocks <= 0:
+        raise ValueError(f"gn_bwd: unsupported channel count {c}")
+    part = torch.empty(n * blocks * c * 2, dtype=torch.float32, device=x.device)
     L.check(L.lib().pti_gn_bwd(_ptr(x), _ptr(da), _ptr(dres), _ptr(dx), _ptr(stats), _ptr(gamma), _ptr(beta),
-                               _ptr(sums), _ptr(dgamma), _ptr(dbeta), n, h * w, c, groups, eps, int(silu),
+                               _ptr(sums), _ptr(part), _ptr(dgamma), _ptr(dbeta), n, h * w, c, groups, eps, int(silu),
                                int(x.dtype == F16), _stream()), "pti_gn_bwd")
     return dx
 
@@ -314,7 +318,8 @@ def gn_bwd(x, da, dx, stats, gamma, beta, sums, dgamma, dbeta, *, groups, eps=1e
 def conv_mfma_gnbwd(dy_in, w_packed_t, gx, gstats, ggamma, gbeta, dy_out, gsums, *, cout, ksize=3, mode=PTI_CONV_S1,
                     groups=0, eps=1e-6, silu=True):
     """Data-gradient conv with the GroupNorm(+SiLU) backward reduction fused into its epilogue:
-    dy_out = conv^T(dy_in) * act'(GN(gx)); gsums[n,c] += {sum dy_out, sum dy_out*xhat} (gsums zeroed by caller)."""
+    dy_out = conv^T(dy_in) * act'(GN(gx)); gsums[n,c] = {sum dy_out, sum dy_out*xhat} (one partial row per pixel tile
+    from the conv, added up in a fixed order by pti_gn_sums_finalize: no float atomics, bitwise reproducible)."""
     _chk(dy_in, BF16, "dy_in", 4)
     _chk(gx, ACT16, "gx", 4)
     _chk(dy_out, BF16, "dy_out", 4)
@@ -327,15 +332,21 @@ def conv_mfma_gnbwd(dy_in, w_packed_t, gx, gstats, ggamma, gbeta, dy_out, gsums,
         raise ValueError("conv_mfma_gnbwd: GroupNorm buffers")
     d = ConvDesc(n=n, h=h, w=w, cin=cin, ho=ho, wo=wo, cout=cout, ksize=ksize, mode=mode, groups=groups, eps=eps,
                  res_f16=int(gx.dtype == F16))
+    tiles = L.lib().pti_conv_gnbwd_tiles(C.byref(d))
+    if tiles <= 0:
+        raise ValueError("conv_mfma_gnbwd: unsupported shape")
+    part = torch.empty(n * tiles * cout * 2, dtype=torch.float32, device=dy_in.device)
     prof = KERNEL_PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     L.check(L.lib().pti_conv2d_mfma_gnbwd(_ptr(dy_in), _ptr(w_packed_t), _ptr(gx), _ptr(gstats), _ptr(ggamma),
-                                          _ptr(gbeta), _ptr(dy_out), _ptr(gsums), C.byref(d), int(silu), _stream()),
+                                          _ptr(gbeta), _ptr(dy_out), _ptr(part), C.byref(d), int(silu), _stream()),
             "pti_conv2d_mfma_gnbwd")
     if prof is not None:
         e1.record()
+    L.check(L.lib().pti_gn_sums_finalize(_ptr(part), _ptr(gsums), n, tiles, 2 * cout, _stream()), "pti_gn_sums_finalize")
+    if prof is not None:
         prof.append((_conv_kernel_name(ksize, mode, cin, cout),
                      2.0 * n * ho * wo * cout * cin * ksize * ksize * (0.25 if mode == PTI_CONV_ZINS else 1.0),
                      2.0 * (dy_in.numel() + 2 * dy_out.numel()), e0, e1))
@@ -394,8 +405,14 @@ def post_quant_bwd(dzq, z_nchw, wp, dz, gwp, gbp):
     _chk(z_nchw, F32, "z")
     if dzq.numel() != z_nchw.numel() or (dz is not None and dz.numel() != z_nchw.numel()):
         raise ValueError("post_quant_bwd: sizes")
-    L.check(L.lib().pti_post_quant_bwd(_ptr(dzq), _ptr(z_nchw), _ptr(wp), _ptr(dz), _ptr(gwp), _ptr(gbp), b, hw, l,
+    ws = torch.empty(POST_QUANT_BWD_MAX_BLOCKS * (l * l + l), dtype=torch.float32, device=dzq.device)
+    L.check(L.lib().pti_post_quant_bwd(_ptr(dzq), _ptr(z_nchw), _ptr(wp), _ptr(dz), _ptr(gwp), _ptr(gbp), _ptr(ws), b, hw, l,
                                        _stream()), "pti_post_quant_bwd")
+
+
+LATENT_BWD_MAX_BLOCKS = 512   # PTI_LATENT_BWD_MAX_BLOCKS / PTI_VAE_LOSS_MAX_BLOCKS of include/pti_vae.h
+VAE_LOSS_MAX_BLOCKS = 1024
+POST_QUANT_BWD_MAX_BLOCKS = 256
 
 
 def latent_head_bwd(h, eps, wm, bm, wl, bl, wp, bp, dzq, dmu, dsigma, dh, gwm, gbm, gwl, gbl, gwp, gbp):
@@ -403,9 +420,11 @@ def latent_head_bwd(h, eps, wm, bm, wl, bl, wp, bp, dzq, dmu, dsigma, dh, gwm, g
     for t in (dzq, dmu, dsigma):
         if t is not None and (t.dtype != F32 or not t.is_contiguous() or t.numel() != b * hw * l):
             raise ValueError("latent_head_bwd: gradient inputs must be contiguous fp32 of the latent size")
+    ws = torch.empty(LATENT_BWD_MAX_BLOCKS * 3 * (l * l + l), dtype=torch.float32, device=h.device)
     L.check(L.lib().pti_latent_head_bwd(_ptr(h), _ptr(eps), _ptr(wm), _ptr(bm), _ptr(wl), _ptr(bl), _ptr(wp), _ptr(bp),
                                         _ptr(dzq), _ptr(dmu), _ptr(dsigma), _ptr(dh), _ptr(gwm), _ptr(gbm), _ptr(gwl),
-                                        _ptr(gbl), _ptr(gwp), _ptr(gbp), b, hw, l, _stream()), "pti_latent_head_bwd")
+                                        _ptr(gbl), _ptr(gwp), _ptr(gbp), _ptr(ws), b, hw, l, _stream()),
+            "pti_latent_head_bwd")
 
 
 def vae_loss(recon, images, mu, third, out2, d_recon, d_mu, d_third, *, l2=False, third_mode=0, kl_weight=1e-3):
@@ -413,8 +432,9 @@ def vae_loss(recon, images, mu, third, out2, d_recon, d_mu, d_third, *, l2=False
         _chk(t, F32, nm)
     if recon.shape != images.shape or mu.shape != third.shape or out2.numel() < 2:
         raise ValueError("vae_loss: shapes")
+    ws = torch.empty(2 * VAE_LOSS_MAX_BLOCKS, dtype=torch.float32, device=recon.device)
     L.check(L.lib().pti_vae_loss(_ptr(recon), _ptr(images), recon.numel(), _ptr(mu), _ptr(third), mu.numel(),
-                                 recon.shape[0], _ptr(out2), _ptr(d_recon), _ptr(d_mu), _ptr(d_third), int(l2),
+                                 recon.shape[0], _ptr(out2), _ptr(d_recon), _ptr(d_mu), _ptr(d_third), _ptr(ws), int(l2),
                                  third_mode, kl_weight, _stream()), "pti_vae_loss")
 
 

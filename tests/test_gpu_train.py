@@ -133,3 +133,29 @@ def test_train_script_checkpoints_and_resume(dev, tmp_path):
     cf.write_text(json.dumps(cfg))
     with pytest.raises(SystemExit):
         train_vae.main(["-c", str(cf), "--synthetic", "8"])
+
+
+@pytest.mark.parametrize("batch,size", [(4, 128), (3, 72)])
+def test_training_steps_are_bitwise_reproducible(dev, batch, size):
+    """Same weights + same batch + same noise -> the SAME bits after three optimiser steps, run after run.  Holds
+    because no floating-point atomics are left on the step's path: GroupNorm statistics are integer fixed-point sums,
+    every other reduction (GroupNorm backward sums, weight-gradient splits, latent-head gradients, loss terms) stores
+    per-workgroup partials and adds them up in a fixed order.  (The weight gradients run on the side stream here, so
+    this also covers the ordering between the two streams.)"""
+    from pti_ldm_vae_amd.trainer import VAETrainer
+    torch.manual_seed(3)
+    x = torch.randn(batch, 1, size, size, device=dev)
+    eps = torch.randn(3, batch, 4, size // 2, size // 2, device=dev)
+    ref = _model(dev)
+    state = {k: v.clone() for k, v in ref.state_dict().items()}
+    runs = []
+    for _ in range(3):
+        m = _model(dev, seed=9)
+        m.load_state_dict(state)
+        tr = VAETrainer(m, lr=1e-3)
+        losses = [tr.step(x, eps[i]) for i in range(3)]
+        torch.cuda.synchronize()
+        runs.append((m.autoencoder.param_arena.clone(), [(o["loss"].item(), o["recon"].item(), o["kl"].item()) for o in losses]))
+    for arena, losses in runs[1:]:
+        assert losses == runs[0][1]
+        assert torch.equal(arena, runs[0][0]), f"max |diff| {(arena - runs[0][0]).abs().max().item():.3e}"
