@@ -271,19 +271,29 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgArgs a) {
 // MFMA loop without loads 52 us, without loads and slabs 44 us -- neither side is near its roof (15 / 20 us) and they
 // overlap only partly.  (tried: an LDS-DMA variant -- x / dy tiles by global_load_lds into a second LDS buffer, no
 // staging registers, no ds_write pass, one barrier per tile, 68 VGPRs -- ran within 1 % of this kernel on every
-// shape; taller tiles (16 rows) +-10 % depending on the shape; 512..2048 workgroups within +-8 %.)
+// shape; taller tiles (16 rows) +-10 % depending on the shape; 512..2048 workgroups within +-8 %; TWO tiles in flight
+// per workgroup -- a second staging register set, loads issued two iterations ahead -- costs the third wave per SIMD
+// (254 VGPRs) and ran 13-22 % slower.)
 // =============================================================================================
+// COB = number of 32-channel co blocks per workgroup (2 when Cout % 64 == 0): every wave then feeds TWO dy fragments
+// per x fragment (6 accumulators, 96 AGPRs): 52 transposing LDS reads per 48 MFMAs instead of 36 per 24, the x halo
+// tile is staged once per 64 output channels instead of once per 32, and there are half as many barriers per MFMA.
+template <int COB>
 struct W3Cfg {
   static constexpr int TH = 8, HH = TH + 2, HW = TW + 2, NP = HH * HW;
   static constexpr int PP = 64;                                  // bytes per pixel (32 channels bf16)
-  static constexpr int A_BYTES = NP * PP, D_BYTES = TH * TW * PP;
+  static constexpr int A_BYTES = NP * PP, DP_BYTES = TH * TW * PP;   // dy: one [pixel][32 co] plane per co block
+  static constexpr int D_BYTES = COB * DP_BYTES;
   static constexpr int NT = 192;
-  static constexpr int HIT = (NP * 4 + NT - 1) / NT, DIT = (TH * TW * 4 + NT - 1) / NT;
+  static constexpr int DPC = 4 * COB;                            // 16-byte pieces per dy pixel
+  static constexpr int HIT = (NP * 4 + NT - 1) / NT, DIT = (TH * TW * DPC + NT - 1) / NT;
   static constexpr int LDS_BYTES = A_BYTES + D_BYTES;
 };
 
-__global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3, 3))) void wgrad_mfma3_kernel(WgArgs a) {   // 3 waves/SIMD: <= 168 VGPR+AGPR
-  using C = W3Cfg;
+template <int COB>
+__global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(COB == 1 ? 3 : 2, COB == 1 ? 3 : 2)))
+void wgrad_mfma3_kernel(WgArgs a) {   // COB 1: 3 waves/SIMD (<= 168 VGPR+AGPR); COB 2: 2 waves/SIMD
+  using C = W3Cfg<COB>;
   typedef short v4s __attribute__((ext_vector_type(4)));
   typedef short v8s __attribute__((ext_vector_type(8)));
   __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS_BYTES];
@@ -295,7 +305,7 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   // id = 8 * (tiles_cc * (split / 8) + cc) + split % 8.  Host guarantees S % 8 == 0 or S < 8 (then id = S * cc + split).
   int split, cc;
   {
-    const int id = blockIdx.x, tiles_cc = a.ci_tiles * (a.Cout / 32);
+    const int id = blockIdx.x, tiles_cc = a.ci_tiles * (a.Cout / (32 * COB));
     if (a.S >= 8) {
       const int k = id >> 3;
       cc = k % tiles_cc;
@@ -306,6 +316,7 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
   }
   const int cot = cc / a.ci_tiles, cit = cc % a.ci_tiles;
+  const int co0 = cot * 32 * COB;
   const bool twox = (a.mode == PTI_CONV_UP2);
   const int VH = twox ? 2 * a.H : a.H, VW = twox ? 2 * a.W : a.W;
 
@@ -313,17 +324,20 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const int pk = 8 * (g >> 1) + q, chl = 16 * (g & 1) + 4 * pp;
   const int fbase = pk * C::PP + chl * 2;
 
-  f32x16 acc[3];
+  f32x16 acc[COB][3];
 #pragma unroll
-  for (int t = 0; t < 3; ++t)
+  for (int h = 0; h < COB; ++h)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[h][t][r] = 0.f;
   float bsum[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
 
-  const int lc = tid & 3, lp = tid >> 2;            // piece within a pixel / pixel index step 48
-  constexpr int PSTEP = C::NT / 4;
+  const int lc = tid & 3, lp = tid >> 2;            // x: piece within a pixel / pixel index, step 48
+  const int lcd = tid % C::DPC, lpd = tid / C::DPC;   // dy: piece within a pixel / pixel index, step NT / DPC
+  constexpr int PSTEP = C::NT / 4, DSTEP = C::NT / C::DPC;
   const int cpg = a.Cin / (a.groups > 0 ? a.groups : 1);
   int cur_n = -1;
   float sc[8], sh[8];
@@ -349,11 +363,11 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
 #pragma unroll
     for (int it = 0; it < C::DIT; ++it) {
-      const int p = lp + it * PSTEP;
+      const int p = lpd + it * DSTEP;
       const int oy = oy0 + p / TW, ox = ox0 + p % TW;
       draw[it] = u32x4{0u, 0u, 0u, 0u};
       if (p < C::TH * TW && oy < a.Ho && ox < a.Wo)
-        draw[it] = *(const u32x4*)(a.dy + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.Cout + cot * 32 + lc * 8);
+        draw[it] = *(const u32x4*)(a.dy + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.Cout + co0 + lcd * 8);
     }
     return n;
   };
@@ -396,9 +410,9 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
 #pragma unroll
     for (int it = 0; it < C::DIT; ++it) {
-      const int p = lp + it * PSTEP;
+      const int p = lpd + it * DSTEP;
       if (p < C::TH * TW) {
-        *(u32x4*)(lD + p * C::PP + lc * 16) = draw[it];
+        *(u32x4*)(lD + (lcd >> 2) * C::DP_BYTES + p * C::PP + (lcd & 3) * 16) = draw[it];
         if (cit == 0) {
           float f[8];
           unpack8(draw[it], f);
@@ -418,17 +432,20 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     if (nxt < a.ntiles) n_next = issue(nxt);
     // Wave kw walks the TH+2 halo rows once: the x fragment of halo row r (column offset kw) meets the dy
     // fragments of output rows r, r-1, r-2 for kernel rows kh = 0, 1, 2.  Each dy fragment is read once and kept for
-    // three rows, each x fragment is read once: 4 transposing LDS reads per 3 MFMAs (wave = kernel row needed 8:
-    // at ~120 KB of LDS traffic per tile the kernel was LDS-bound, not MFMA-bound).
-    bf16x8 dfr[C::TH];
+    // three rows, each x fragment is read once: 4 transposing LDS reads per 3 MFMAs at COB = 1, 6 per 6 at COB = 2
+    // (wave = kernel row needed 8 per 3: at ~120 KB of LDS traffic per tile the kernel was LDS-bound, not MFMA-bound).
+    bf16x8 dfr[COB][C::TH];
 #pragma unroll
     for (int r = 0; r < C::TH + 2; ++r) {
       if (r < C::TH) {
-        const unsigned char* dptr = lD + fbase + r * TW * C::PP;
-        const v4s d0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(dptr));
-        const v4s d1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(dptr + 4 * C::PP));
-        v8s td = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
-        dfr[r] = __builtin_bit_cast(bf16x8, td);
+#pragma unroll
+        for (int h = 0; h < COB; ++h) {
+          const unsigned char* dptr = lD + h * C::DP_BYTES + fbase + r * TW * C::PP;
+          const v4s d0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(dptr));
+          const v4s d1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(dptr + 4 * C::PP));
+          v8s td = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+          dfr[h][r] = __builtin_bit_cast(bf16x8, td);
+        }
       }
       const unsigned char* aptr = lA + fbase + (r * C::HW + kw) * C::PP;
       const v4s a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(aptr));
@@ -438,7 +455,11 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh) {
         const int o = r - kh;          // output row whose halo row o + kh is r
-        if (o >= 0 && o < C::TH) acc[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfr[o], afr, acc[kh], 0, 0, 0);
+        if (o >= 0 && o < C::TH) {
+#pragma unroll
+          for (int h = 0; h < COB; ++h)
+            acc[h][kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfr[h][o], afr, acc[h][kh], 0, 0, 0);
+        }
       }
     }
     __syncthreads();
@@ -449,22 +470,24 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const int ci = cit * 32 + (lane & 31);
   const int hsel = lane >> 5;
 #pragma unroll
-  for (int kh = 0; kh < 3; ++kh)
+  for (int h = 0; h < COB; ++h)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = cot * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
-      slab[((size_t)(kh * 3 + kw) * a.Cout + co) * a.Cin + ci] = acc[kh][r];
-    }
-  if (cit == 0) {   // bias partials: threads with equal lc hold the same 8 channels
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + h * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
+        slab[((size_t)(kh * 3 + kw) * a.Cout + co) * a.Cin + ci] = acc[h][kh][r];
+      }
+  if (cit == 0) {   // bias partials: threads with equal lcd hold the same 8 channels
     float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int j = 0; j < 8; ++j) red[j * C::NT + tid] = bsum[j];
     __syncthreads();
-    if (tid < 32) {
-      const int c4 = tid / 8, j = tid % 8;
+    if (tid < 32 * COB) {
+      const int c8 = tid / 8, j = tid % 8;
       float sm = 0.f;
-      for (int k = c4; k < C::NT; k += 4) sm += red[j * C::NT + k];
-      slab[(size_t)9 * a.Cout * a.Cin + cot * 32 + tid] = sm;
+      for (int k = c8; k < C::NT; k += C::DPC) sm += red[j * C::NT + k];
+      slab[(size_t)9 * a.Cout * a.Cin + co0 + tid] = sm;
     }
   }
 }
@@ -558,15 +581,24 @@ extern "C" int pti_conv_wgrad_mfma_partials(const void* x, const void* dy, const
   int co_t = d->cout % 64 == 0 ? 64 : 32, ci_t = d->cin % 64 == 0 ? 64 : 32;
   if ((long long)a.ntiles * (d->cout / co_t) * (d->cin / ci_t) < 16 * 512) co_t = ci_t = 32;
   const bool v3 = d->ksize == 3 && d->mode != PTI_CONV_S2PAD;
-  if (v3) co_t = ci_t = 32;
+  // Two co blocks per workgroup when the GroupNorm+SiLU prologue runs in the loader (it is then done once per 64
+  // output channels: 64->64@128^2 129 -> 96 us, 128->128@64^2 125 -> 94 us).  On saved, already activated inputs
+  // (the training step's default) it measured 69.2 -> 67.2 / 68.0 -> 66.3 us in isolation but +0.7 % per step when
+  // overlapped with the data-gradient chain (2 waves/SIMD co-schedule worse), and the nearest-2x gather ran 3-10 %
+  // slower with it: those keep one block.  PTI_WGRAD_COB=1|2 forces the choice (tuning knob).
+  static const int cob_env = getenv("PTI_WGRAD_COB") ? atoi(getenv("PTI_WGRAD_COB")) : 0;
+  const bool cob_ok = d->cout % 64 == 0 && d->mode == PTI_CONV_S1;
+  const int cob = (cob_ok && cob_env != 1 && (cob_env == 2 || d->prologue != PTI_PRO_NONE)) ? 2 : 1;
+  if (v3) { ci_t = 32; co_t = 32 * cob; }
   a.ci_tiles = d->cin / ci_t;
   const int tiles_cc = (d->cout / co_t) * a.ci_tiles;
   const int kk = d->ksize * d->ksize;
   a.slab_stride = (long long)kk * d->cout * d->cin + d->cout;
   const long long smax = workspace_bytes / (a.slab_stride * 4);
   // v3: three waves per workgroup; 768 workgroups = 3 per CU measured best (512 .. 2048 within +-8 %: fewer
-  // workgroups mean fewer 37-KB partial slabs to write and reduce, more mean more loads in flight)
-  int S = (v3 ? 768 : 512) / tiles_cc;
+  // workgroups mean fewer 37-KB partial slabs to write and reduce, more mean more loads in flight); with two co
+  // blocks (2 waves/SIMD) 512 = 2 per CU (768 / 1024: +25 %, 384: +17 %)
+  int S = (v3 ? (cob == 2 ? 512 : 768) : 512) / tiles_cc;
   if (S > a.ntiles / 4) S = a.ntiles / 4;
   if (S > (v3 ? 512 : 256)) S = v3 ? 512 : 256;
   if (S < 1) S = 1;
@@ -575,7 +607,8 @@ extern "C" int pti_conv_wgrad_mfma_partials(const void* x, const void* dy, const
   if (v3 && S >= 8) S &= ~7;   // whole rounds over the 8 XCDs (see the block-order note in the kernel)
   a.S = S;
   hipStream_t st = (hipStream_t)s;
-  if (v3) hipLaunchKernelGGL(wgrad_mfma3_kernel, dim3(tiles_cc * S), dim3(192), 0, st, a);
+  if (v3 && cob == 2) hipLaunchKernelGGL(wgrad_mfma3_kernel<2>, dim3(tiles_cc * S), dim3(192), 0, st, a);
+  else if (v3) hipLaunchKernelGGL(wgrad_mfma3_kernel<1>, dim3(tiles_cc * S), dim3(192), 0, st, a);
   else if (d->ksize == 1) launch_wt<1, 1>(a, co_t, ci_t, tiles_cc, st);
   else launch_wt<3, 2>(a, co_t, ci_t, tiles_cc, st);
   PTI_CHECK_LAUNCH("conv_wgrad_mfma");
