@@ -429,9 +429,16 @@ struct Cfg2 {
   static constexpr int LDS_BYTES = RT_OFF + RT_BYTES;
 };
 
-template <int KS, int CK, int CT, int PXF, bool SAVE>
+// FM = storage-format mode: 0 = the three 16-bit formats are run-time flags; 1 = input, residual and output are all
+// fp16 (every forward conv of the default engine), 2 = all bf16 (plain data gradients), 3 = bf16 in / fp16 residual /
+// bf16 out (data gradient fused with the GroupNorm backward: the "residual" is the fp16 GN input).  Known formats
+// drop the convert-both-ways-and-select per element (the narrow-layer convs are VALU-bound).
+template <int KS, int CK, int CT, int PXF, bool SAVE, int FM>
 __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(ConvArgs a) {
   using C = Cfg2<KS, CK, CT, PXF>;
+  const bool in_f16 = FM == 0 ? (bool)a.in_f16 : (FM == 1);
+  const bool res_f16 = FM == 0 ? (bool)a.res_f16 : (FM == 1 || FM == 3);
+  const bool out_f16 = FM == 0 ? (bool)a.out_f16 : (FM == 1);
   __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS_BYTES];
   unsigned char* halo = smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -565,7 +572,7 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
         u32x4 r = raw[it];
         if (a.prologue != PTI_PRO_NONE && ok[it]) {
           float f[8];
-          unpack8f(r, f, a.in_f16);
+          unpack8f(r, f, in_f16);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             float v = f[j] * sc[j] + sh[j];
@@ -573,7 +580,7 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
             f[j] = v;
           }
           r = pack8(f);
-        } else if (a.in_f16) {   // no prologue: the MFMA operand is bf16, convert the fp16 piece
+        } else if (in_f16) {   // no prologue: the MFMA operand is bf16, convert the fp16 piece
           float f[8];
           unpack8f(r, f, true);
           r = pack8(f);
@@ -695,8 +702,8 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
         unsigned char* ep = etile + p * C::EPITCH + col * 2;
         const u32x2 rr = *(const u32x2*)(rtile + p * (CT * 2) + ((((col >> 3) ^ (p >> 2)) & (C::ENC - 1)) << 4) + (col & 7) * 2);
         float xv[4];
-        unpack2f(rr[0], a.res_f16, xv[0], xv[1]);
-        unpack2f(rr[1], a.res_f16, xv[2], xv[3]);
+        unpack2f(rr[0], res_f16, xv[0], xv[1]);
+        unpack2f(rr[1], res_f16, xv[2], xv[3]);
         float dv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -745,16 +752,16 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
       if (a.res) {
         const u32x2 rr = *(const u32x2*)(rtile + p * (CT * 2) + ((((col >> 3) ^ (p >> 2)) & (C::ENC - 1)) << 4) + (col & 7) * 2);
         float e0, e1, e2, e3;
-        unpack2f(rr[0], a.res_f16, e0, e1);
-        unpack2f(rr[1], a.res_f16, e2, e3);
+        unpack2f(rr[0], res_f16, e0, e1);
+        unpack2f(rr[1], res_f16, e2, e3);
         v0 += e0; v1 += e1; v2 += e2; v3 += e3;
       }
-      const u32x2 packed = pack4f(v0, v1, v2, v3, a.out_f16);
+      const u32x2 packed = pack4f(v0, v1, v2, v3, out_f16);
       *(u32x2*)ep = packed;
       if (do_stats && inb) {
         float r0, r1, r2, r3;
-        unpack2f(packed[0], a.out_f16, r0, r1);
-        unpack2f(packed[1], a.out_f16, r2, r3);
+        unpack2f(packed[0], out_f16, r0, r1);
+        unpack2f(packed[1], out_f16, r2, r3);
         if (ocpg >= 4) {
           st1[q] += (r0 + r1) + (r2 + r3);
           st2[q] += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
@@ -807,17 +814,17 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
       if (pp < C::MPX / 4 && oy < (a.Ho >> 1) && ox < (a.Wo >> 1)) {
         const unsigned char* src = etile + ((2 * py) * 16 + 2 * px) * C::EPITCH + c8 * 16;
         float s_[8], f_[8];
-        unpack8f(*(const u32x4*)src, s_, a.out_f16);
-        unpack8f(*(const u32x4*)(src + C::EPITCH), f_, a.out_f16);
+        unpack8f(*(const u32x4*)src, s_, out_f16);
+        unpack8f(*(const u32x4*)(src + C::EPITCH), f_, out_f16);
 #pragma unroll
         for (int q = 0; q < 8; ++q) s_[q] += f_[q];
-        unpack8f(*(const u32x4*)(src + 16 * C::EPITCH), f_, a.out_f16);
+        unpack8f(*(const u32x4*)(src + 16 * C::EPITCH), f_, out_f16);
 #pragma unroll
         for (int q = 0; q < 8; ++q) s_[q] += f_[q];
-        unpack8f(*(const u32x4*)(src + 17 * C::EPITCH), f_, a.out_f16);
+        unpack8f(*(const u32x4*)(src + 17 * C::EPITCH), f_, out_f16);
 #pragma unroll
         for (int q = 0; q < 8; ++q) s_[q] += f_[q];
-        __builtin_nontemporal_store(pack8f(s_, a.out_f16),
+        __builtin_nontemporal_store(pack8f(s_, out_f16),
                                     (u32x4*)(a.y + ((size_t)(n * (a.Ho >> 1) + oy) * (a.Wo >> 1) + ox) * a.Cout + ct * CT + c8 * 8));
       }
     }
@@ -855,15 +862,23 @@ int launch2_cfg(ConvArgs a, hipStream_t st) {
   a.tiles_y = cdiv(a.Ho, C::TH2);
   a.g_T = a.tiles_x * a.tiles_y;
   dim3 grid(a.N * a.tiles_x * a.tiles_y, a.Cout / CT);
+  const bool res = a.res != nullptr;
+  const int fm = (a.in_f16 && a.out_f16 && (a.res_f16 || !res)) ? 1
+               : (!a.in_f16 && !a.out_f16 && (!a.res_f16 || !res)) ? 2
+               : (!a.in_f16 && !a.out_f16 && a.res_f16) ? 3 : 0;
   if constexpr (KS == 3) {   // the activated-input side output is a separate instantiation (3x3 only)
     if (a.act_out) {
-      hipLaunchKernelGGL((conv_mfma2_kernel<KS, CK, CT, PXF, true>), grid, dim3(256), 0, st, a);
+      if (fm == 1) hipLaunchKernelGGL((conv_mfma2_kernel<KS, CK, CT, PXF, true, 1>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((conv_mfma2_kernel<KS, CK, CT, PXF, true, 0>), grid, dim3(256), 0, st, a);
       return 0;
     }
   } else if (a.act_out) {
     return 1;
   }
-  hipLaunchKernelGGL((conv_mfma2_kernel<KS, CK, CT, PXF, false>), grid, dim3(256), 0, st, a);
+  if (fm == 1) hipLaunchKernelGGL((conv_mfma2_kernel<KS, CK, CT, PXF, false, 1>), grid, dim3(256), 0, st, a);
+  else if (fm == 2) hipLaunchKernelGGL((conv_mfma2_kernel<KS, CK, CT, PXF, false, 2>), grid, dim3(256), 0, st, a);
+  else if (fm == 3) hipLaunchKernelGGL((conv_mfma2_kernel<KS, CK, CT, PXF, false, 3>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((conv_mfma2_kernel<KS, CK, CT, PXF, false, 0>), grid, dim3(256), 0, st, a);
   return 0;
 }
 template <int KS>

@@ -11,6 +11,7 @@ from pti_ldm_vae_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
 B = 32
+ADT = torch.float16 if os.environ.get("BENCH_ACT", "bf16") == "fp16" else torch.bfloat16   # forward storage format
 SHAPES = [  # cin, cout, h, w, mode
     (32, 32, 256, 256, ops.PTI_CONV_S1), (64, 64, 128, 128, ops.PTI_CONV_S1), (128, 128, 64, 64, ops.PTI_CONV_S1),
     (128, 128, 32, 32, ops.PTI_CONV_S1), (64, 32, 256, 256, ops.PTI_CONV_S1), (64, 64, 128, 128, ops.PTI_CONV_UP2),
@@ -35,13 +36,13 @@ def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     G = 16
     for cin, cout, h, w, mode in SHAPES:
-        x = torch.randn(B, h, w, cin, device=dev).to(torch.bfloat16)
+        x = torch.randn(B, h, w, cin, device=dev).to(ADT if what == "fwd" else torch.bfloat16)
         wt = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
         bias = torch.zeros(cout, device=dev)
         gamma, beta = torch.ones(cin, device=dev), torch.zeros(cin, device=dev)
         wp = ops.pack_conv_weight(wt, 3, mode)
         ho, wo = ops.conv_out_hw(h, w, mode)
-        y = torch.empty(B, ho, wo, cout, dtype=torch.bfloat16, device=dev)
+        y = torch.empty(B, ho, wo, cout, dtype=ADT if what == "fwd" else torch.bfloat16, device=dev)
         res = torch.randn_like(y)
         st = ops.gn_stats(x, G)
         ost = torch.zeros(B, G, 2, dtype=torch.int64, device=dev)
