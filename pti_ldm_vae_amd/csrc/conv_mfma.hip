@@ -433,9 +433,14 @@ struct Cfg2 {
 // fp16 (every forward conv of the default engine), 2 = all bf16 (plain data gradients), 3 = bf16 in / fp16 residual /
 // bf16 out (data gradient fused with the GroupNorm backward: the "residual" is the fp16 GN input).  Known formats
 // drop the convert-both-ways-and-select per element (the narrow-layer convs are VALU-bound).
-template <int KS, int CK, int CT, int PXF, bool SAVE, int FM>
+// PRO = the prologue when known at compile time (PTI_PRO_NONE / PTI_PRO_GN_SILU), -1 = run-time.  Modes 2 and 3 are
+// data gradients (no prologue); mode 3 IS the fused GroupNorm-backward epilogue, modes 1 and 2 never are: the
+// unused prologue / epilogue code and its registers (16 scale/shift VGPRs at the 128-VGPR cap) disappear.
+template <int KS, int CK, int CT, int PXF, bool SAVE, int FM, int PRO>
 __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(ConvArgs a) {
   using C = Cfg2<KS, CK, CT, PXF>;
+  const int prologue = PRO >= 0 ? PRO : a.prologue;
+  const bool gn_on = FM == 3 ? true : (FM == 0 ? a.gn_mode != 0 : false);
   const bool in_f16 = FM == 0 ? (bool)a.in_f16 : (FM == 1);
   const bool res_f16 = FM == 0 ? (bool)a.res_f16 : (FM == 1 || FM == 3);
   const bool out_f16 = FM == 0 ? (bool)a.out_f16 : (FM == 1);
@@ -483,9 +488,9 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
   // 2*G threads convert the fixed-point values once instead of every thread converting the ones its channels need
   // (256 B behind the 1-KiB accumulator area, so groups <= 32)
   float* sfl = reinterpret_cast<float*>(smem + C::STAT_OFF + 1024);
-  if (a.prologue != PTI_PRO_NONE) {
+  if (prologue != PTI_PRO_NONE) {
     if (tid < 2 * a.groups) sfl[tid] = stat_f(a.in_stats, n * a.groups * 2 + tid);
-  } else if (a.gn_mode) {
+  } else if (gn_on) {
     if (tid < 2 * a.g_groups) sfl[tid] = stat_f(a.g_stats, n * a.g_groups * 2 + tid);
   }
   if (a.res) {
@@ -551,7 +556,7 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
     // statistics / gamma / beta round trips (L2) overlap the halo's HBM round trip instead of preceding it
     if (chunk == 0) __syncthreads();   // the float statistics table (sfl) is complete
     float sc[8], sh[8];
-    if (a.prologue != PTI_PRO_NONE) {
+    if (prologue != PTI_PRO_NONE) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int ch = chunk * CK + lc * 8 + j;
@@ -570,13 +575,13 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
       if (p < C::NP) {
         const int hy = p / C::HW, hx = p - hy * C::HW;
         u32x4 r = raw[it];
-        if (a.prologue != PTI_PRO_NONE && ok[it]) {
+        if (prologue != PTI_PRO_NONE && ok[it]) {
           float f[8];
           unpack8f(r, f, in_f16);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             float v = f[j] * sc[j] + sh[j];
-            if (a.prologue == PTI_PRO_GN_SILU) v = silu_f(v);
+            if (prologue == PTI_PRO_GN_SILU) v = silu_f(v);
             f[j] = v;
           }
           r = pack8(f);
@@ -676,7 +681,7 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
   const int col0 = wn * 32 + 4 * hsel;   // channel within the CT tile
   float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f};   // per quad q (or first pair when ocpg==2)
   float su1[4] = {0.f, 0.f, 0.f, 0.f}, su2[4] = {0.f, 0.f, 0.f, 0.f};   // second pair of the quad when ocpg==2
-  if (a.gn_mode) {
+  if (gn_on) {
     // (B') data gradient + GroupNorm backward reduction: etile holds the GN input gx
     const int gcpg = a.Cout / a.g_groups;
     float* gsm = reinterpret_cast<float*>(smem + C::STAT_OFF);   // [WM][CT][2]: one slot per (pixel group, channel, sum)
@@ -838,7 +843,7 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
       __builtin_nontemporal_store(*(const u32x4*)(etile + p * C::EPITCH + epc * 16),
                                   (u32x4*)(a.y + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.Cout + ct * CT + epc * 8));
   }
-  if (a.gn_mode) {
+  if (gn_on) {
     if (tid < 2 * CT) {
       const float* gsm = reinterpret_cast<const float*>(smem + C::STAT_OFF);
       float v = gsm[tid];
@@ -866,19 +871,29 @@ int launch2_cfg(ConvArgs a, hipStream_t st) {
   const int fm = (a.in_f16 && a.out_f16 && (a.res_f16 || !res)) ? 1
                : (!a.in_f16 && !a.out_f16 && (!a.res_f16 || !res)) ? 2
                : (!a.in_f16 && !a.out_f16 && a.res_f16) ? 3 : 0;
+  // compile-time specialisations the engine's launches hit (anything else: the run-time-flag instantiation)
+  const bool fwd_silu = fm == 1 && a.prologue == PTI_PRO_GN_SILU && !a.gn_mode;
+  const bool fwd_plain = fm == 1 && a.prologue == PTI_PRO_NONE && !a.gn_mode;
+  const bool dgrad = fm == 2 && a.prologue == PTI_PRO_NONE && !a.gn_mode;
+  const bool dgrad_gn = fm == 3 && a.prologue == PTI_PRO_NONE && a.gn_mode;
+  // forward GroupNorm+SiLU launches: the prologue is a compile-time constant only for the 2-workgroup/CU shapes; at
+  // the 128-VGPR cap of the others it made the compiler interleave the SiLU chains and spill (32->32@256^2 +res+stats
+  // 153 -> 184 us), so those keep the run-time prologue flag (but the compile-time formats)
+  constexpr int FPRO = PXF == 4 ? PTI_PRO_GN_SILU : -1;
   if constexpr (KS == 3) {   // the activated-input side output is a separate instantiation (3x3 only)
     if (a.act_out) {
-      if (fm == 1) hipLaunchKernelGGL((conv_mfma2_kernel<KS, CK, CT, PXF, true, 1>), grid, dim3(256), 0, st, a);
-      else hipLaunchKernelGGL((conv_mfma2_kernel<KS, CK, CT, PXF, true, 0>), grid, dim3(256), 0, st, a);
+      if (fwd_silu) hipLaunchKernelGGL((conv_mfma2_kernel<KS, CK, CT, PXF, true, 1, FPRO>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((conv_mfma2_kernel<KS, CK, CT, PXF, true, 0, -1>), grid, dim3(256), 0, st, a);
       return 0;
     }
   } else if (a.act_out) {
     return 1;
   }
-  if (fm == 1) hipLaunchKernelGGL((conv_mfma2_kernel<KS, CK, CT, PXF, false, 1>), grid, dim3(256), 0, st, a);
-  else if (fm == 2) hipLaunchKernelGGL((conv_mfma2_kernel<KS, CK, CT, PXF, false, 2>), grid, dim3(256), 0, st, a);
-  else if (fm == 3) hipLaunchKernelGGL((conv_mfma2_kernel<KS, CK, CT, PXF, false, 3>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((conv_mfma2_kernel<KS, CK, CT, PXF, false, 0>), grid, dim3(256), 0, st, a);
+  if (fwd_silu) hipLaunchKernelGGL((conv_mfma2_kernel<KS, CK, CT, PXF, false, 1, FPRO>), grid, dim3(256), 0, st, a);
+  else if (fwd_plain) hipLaunchKernelGGL((conv_mfma2_kernel<KS, CK, CT, PXF, false, 1, PTI_PRO_NONE>), grid, dim3(256), 0, st, a);
+  else if (dgrad) hipLaunchKernelGGL((conv_mfma2_kernel<KS, CK, CT, PXF, false, 2, PTI_PRO_NONE>), grid, dim3(256), 0, st, a);
+  else if (dgrad_gn) hipLaunchKernelGGL((conv_mfma2_kernel<KS, CK, CT, PXF, false, 3, PTI_PRO_NONE>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((conv_mfma2_kernel<KS, CK, CT, PXF, false, 0, -1>), grid, dim3(256), 0, st, a);
   return 0;
 }
 template <int KS>

@@ -11,6 +11,9 @@ the step path: loss scalars come back as device tensors.
 """
 from __future__ import annotations
 
+import collections
+import os
+
 import torch
 
 from . import ops
@@ -40,11 +43,19 @@ class VAETrainer:
         self.gen = torch.Generator(device=net.param_arena.device)
         self.gen.manual_seed(42 + rank_eps_offset)
         self.eng.grad_ready_cb = None
+        # the host enqueues a step in about half the time the GPU needs for it; left alone it runs ahead until the
+        # HIP queues saturate, and that showed up as ONE 0.3-0.5 s host stall some 15 steps into a run
+        # (tools/step_jitter.py).  The step therefore waits for the step issued `max_steps_in_flight` steps earlier:
+        # the GPU always has the next step queued, the host never gets further ahead than that.
+        self.max_steps_in_flight = int(os.environ.get("PTI_MAX_STEPS_IN_FLIGHT", "2"))
+        self._step_done = collections.deque()
 
     def step(self, images: torch.Tensor, eps: torch.Tensor | None = None):
         """One optimiser step on ``images`` [B,C,H,W] fp32 (already on the device).  Returns a dict of
-        DEVICE scalars {"loss", "recon", "kl"} (no host sync)."""
+        DEVICE scalars {"loss", "recon", "kl"} (no host sync with THIS step; see ``max_steps_in_flight``)."""
         net, eng, red = self.net, self.eng, self.reducer
+        while len(self._step_done) >= max(1, self.max_steps_in_flight):
+            self._step_done.popleft().synchronize()
         net.grad_arena.zero_()
         red.begin_step()
         eng.grad_ready_cb = red.ready if self.world > 1 else None
@@ -69,6 +80,9 @@ class VAETrainer:
         finally:
             eng.grad_ready_cb = None
         self.opt.step(grad_scale=1.0 / self.world)
+        done = torch.cuda.Event()
+        done.record()
+        self._step_done.append(done)
         return {"loss": out2[0] + self.kl_weight * out2[1], "recon": out2[0], "kl": out2[1]}
 
     @torch.no_grad()
