@@ -673,7 +673,7 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
   // ---- epilogue: bias, residual, bf16 rounding, optional GroupNorm statistics, coalesced store ----
   const int j = lane & 31;
   unsigned char* etile = smem;
-  const bool do_stats = a.out_stats != nullptr;
+  const bool do_stats = (FM == 2 || FM == 3) ? false : a.out_stats != nullptr;   // data gradients feed no GroupNorm
   const int ocpg = do_stats ? a.Cout / a.out_groups : 1;
   __syncthreads();  // every wave is done with the halo tile
   // (A) the residual tile is already in LDS (rtile, LDS-DMA issued at kernel start; every barrier since drained it)
@@ -805,7 +805,7 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
   }
   __syncthreads();
   // (C) LDS tile -> global, 16 bytes per lane, consecutive lanes on consecutive addresses
-  if (a.pool2) {
+  if ((FM == 0 || FM == 2) && a.pool2) {   // pooled output: plain data gradients only
     // data gradient of  conv(nearest-2x(x)): the gradient w.r.t. x is the 2x2 sum of the gradient w.r.t. the
     // up-sampled map -- summed here (fp32) from the LDS tile instead of writing the full-resolution map and
     // pooling it in a second pass.  Tile origins and sizes are even, so every 2x2 cell lies inside one tile.
@@ -872,10 +872,10 @@ int launch2_cfg(ConvArgs a, hipStream_t st) {
                : (!a.in_f16 && !a.out_f16 && (!a.res_f16 || !res)) ? 2
                : (!a.in_f16 && !a.out_f16 && a.res_f16) ? 3 : 0;
   // compile-time specialisations the engine's launches hit (anything else: the run-time-flag instantiation)
-  const bool fwd_silu = fm == 1 && a.prologue == PTI_PRO_GN_SILU && !a.gn_mode;
-  const bool fwd_plain = fm == 1 && a.prologue == PTI_PRO_NONE && !a.gn_mode;
-  const bool dgrad = fm == 2 && a.prologue == PTI_PRO_NONE && !a.gn_mode;
-  const bool dgrad_gn = fm == 3 && a.prologue == PTI_PRO_NONE && a.gn_mode;
+  const bool fwd_silu = fm == 1 && a.prologue == PTI_PRO_GN_SILU && !a.gn_mode && !a.pool2;
+  const bool fwd_plain = fm == 1 && a.prologue == PTI_PRO_NONE && !a.gn_mode && !a.pool2;
+  const bool dgrad = fm == 2 && a.prologue == PTI_PRO_NONE && !a.gn_mode && !a.out_stats;
+  const bool dgrad_gn = fm == 3 && a.prologue == PTI_PRO_NONE && a.gn_mode && !a.out_stats && !a.pool2;
   // forward GroupNorm+SiLU launches: the prologue is a compile-time constant only for the 2-workgroup/CU shapes; at
   // the 128-VGPR cap of the others it made the compiler interleave the SiLU chains and spill (32->32@256^2 +res+stats
   // 153 -> 184 us), so those keep the run-time prologue flag (but the compile-time formats)
