@@ -578,11 +578,22 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
         if (prologue != PTI_PRO_NONE && ok[it]) {
           float f[8];
           unpack8f(r, f, in_f16);
+          if (PXF == 4 && prologue == PTI_PRO_GN_SILU) {
+            // packed-fp32 form: -3..-5 % on the 2-workgroup/CU shapes; at the 128-VGPR cap of the others it spills
+            // (32->32@256^2 +res+stats 152 -> 162 us), they take the scalar form below
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            float v = f[j] * sc[j] + sh[j];
-            if (prologue == PTI_PRO_GN_SILU) v = silu_f(v);
-            f[j] = v;
+            for (int j = 0; j < 8; j += 2) {
+              const f32x2 o = gn_silu2(f32x2{f[j], f[j + 1]}, f32x2{sc[j], sc[j + 1]}, f32x2{sh[j], sh[j + 1]});
+              f[j] = o[0];
+              f[j + 1] = o[1];
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              float v = f[j] * sc[j] + sh[j];
+              if (prologue == PTI_PRO_GN_SILU) v = silu_f(v);
+              f[j] = v;
+            }
           }
           r = pack8(f);
         } else if (in_f16) {   // no prologue: the MFMA operand is bf16, convert the fp16 piece

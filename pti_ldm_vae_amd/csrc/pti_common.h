@@ -130,6 +130,22 @@ __device__ __forceinline__ float dsilu_f(float v) {
   return s * (1.0f + v * (1.0f - s));
 }
 
+// SiLU(x * sc + sh) of two elements with the packed-fp32 VALU ops (v_pk_fma / v_pk_mul / v_pk_add: two lanes-worth per
+// issue) around the two transcendentals each element needs (v_exp_f32, v_rcp_f32): 4 packed + 4 scalar issues per
+// PAIR instead of 6 scalar issues per element.  The narrow-layer convs are VALU-bound in their GroupNorm+SiLU loader.
+__device__ __forceinline__ f32x2 gn_silu2(f32x2 x, f32x2 sc, f32x2 sh) {
+  const f32x2 v = x * sc + sh;
+  const f32x2 t = v * -1.4426950408889634f;   // exp(-v) = 2^(-v * log2 e)
+  f32x2 e;
+  e[0] = __builtin_amdgcn_exp2f(t[0]);
+  e[1] = __builtin_amdgcn_exp2f(t[1]);
+  const f32x2 d = e + 1.0f;
+  f32x2 r;
+  r[0] = __builtin_amdgcn_rcpf(d[0]);
+  r[1] = __builtin_amdgcn_rcpf(d[1]);
+  return v * r;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
