@@ -100,7 +100,8 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--config", default=os.path.join(ROOT, "config", "vae_dente_no_adv.json"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=16,
+                    help="timed oracle steps of the cpu_baseline leg (batch 4: ~10 s of CPU work on 16 cores)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -236,7 +237,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline (oracle) ...")
-            line["cpu_baseline"] = cpu_baseline(cfg_def, args.size, 2, args.cpu_steps)
+            line["cpu_baseline"] = cpu_baseline(cfg_def, args.size, 4, args.cpu_steps)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

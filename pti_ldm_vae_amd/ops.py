@@ -149,7 +149,9 @@ def conv_mfma(x, w_packed, bias, y, *, cout, ksize=3, mode=PTI_CONV_S1, prologue
                 "pti_conv2d_mfma")
     if prof is not None:
         e1.record()
-        name = _conv_kernel_name(ksize, mode, cin, cout, act_out is not None)
+        name = _conv_kernel_name(ksize, mode, cin, cout, act_out is not None, in_f16=x.dtype == F16, out_f16=y.dtype == F16,
+                                 res=residual is not None, res_f16=residual is not None and residual.dtype == F16,
+                                 prologue=prologue, pool2=pool2, stats=out_stats is not None)
         # algorithmic work; the zero-insert data gradient only has 1/4 useful taps per output pixel
         flops = 2.0 * n * ho * wo * cout * cin * ksize * ksize * (0.25 if mode == PTI_CONV_ZINS else 1.0)
         # algorithmic bytes: read the input once (bf16), write the output once (+ residual read)
@@ -158,13 +160,37 @@ def conv_mfma(x, w_packed, bias, y, *, cout, ksize=3, mode=PTI_CONV_S1, prologue
     return y
 
 
-def _conv_kernel_name(ksize, mode, cin, cout, save=False):
-    """Template instantiation the C side picks (mirrors pick_cout_tile / pick_ck / pick_ck2), as rocprof names it."""
+def _conv_kernel_name(ksize, mode, cin, cout, save=False, *, in_f16=False, out_f16=False, res=False, res_f16=False,
+                      prologue=PTI_PRO_NONE, gn=False, pool2=False, stats=False):
+    """Template instantiation the C side picks (mirrors pick_cout_tile / pick_ck / pick_ck2 and launch2_cfg's choice
+    of the storage-format / prologue specialisation), as rocprof names it."""
     ct = 128 if cout % 128 == 0 else (64 if cout % 64 == 0 else 32)
     ck = 128 if cin % 128 == 0 else (64 if cin % 64 == 0 else 32)
     if mode == PTI_CONV_S2PAD:
         return f"conv_mfma_kernel<3, 2, {min(ck, 64)}, {ct}>"
-    return f"conv_mfma2_kernel<{ksize}, {min(ck, ct)}, {ct}, {4 if ct == 128 else 2}, {str(save).lower()}>"
+    pxf = 4 if ct == 128 else 2
+    if in_f16 and out_f16 and (res_f16 or not res):
+        fm = 1
+    elif not in_f16 and not out_f16 and (not res_f16 or not res):
+        fm = 2
+    elif not in_f16 and not out_f16 and res_f16:
+        fm = 3
+    else:
+        fm = 0
+    fpro = PTI_PRO_GN_SILU if pxf == 4 else -1
+    if fm == 1 and prologue == PTI_PRO_GN_SILU and not gn and not pool2:
+        spec = (1, fpro)
+    elif save and ksize == 3:
+        spec = (0, -1)
+    elif fm == 1 and prologue == PTI_PRO_NONE and not gn and not pool2:
+        spec = (1, PTI_PRO_NONE)
+    elif fm == 2 and prologue == PTI_PRO_NONE and not gn and not stats:
+        spec = (2, PTI_PRO_NONE)
+    elif fm == 3 and prologue == PTI_PRO_NONE and gn and not stats and not pool2:
+        spec = (3, PTI_PRO_NONE)
+    else:
+        spec = (0, -1)
+    return f"conv_mfma2_kernel<{ksize}, {min(ck, ct)}, {ct}, {pxf}, {str(bool(save)).lower()}, {spec[0]}, {spec[1]}>"
 
 
 # Set to a list to make conv_mfma record (kernel name, algorithmic flops, bytes, start, end events) per
@@ -350,7 +376,8 @@ def conv_mfma_gnbwd(dy_in, w_packed_t, gx, gstats, ggamma, gbeta, dy_out, gsums,
         e1.record()
     L.check(L.lib().pti_gn_sums_finalize(_ptr(part), _ptr(gsums), n, tiles, 2 * cout, _stream()), "pti_gn_sums_finalize")
     if prof is not None:
-        prof.append((_conv_kernel_name(ksize, mode, cin, cout),
+        prof.append((_conv_kernel_name(ksize, mode, cin, cout, in_f16=dy_in.dtype == F16, out_f16=dy_out.dtype == F16, res=True,
+                                       res_f16=gx.dtype == F16, gn=True),
                      2.0 * n * ho * wo * cout * cin * ksize * ksize * (0.25 if mode == PTI_CONV_ZINS else 1.0),
                      2.0 * (dy_in.numel() + 2 * dy_out.numel()), e0, e1))
     return dy_out
