@@ -889,7 +889,9 @@ int launch2_cfg(ConvArgs a, hipStream_t st) {
   const bool dgrad_gn = fm == 3 && a.prologue == PTI_PRO_NONE && a.gn_mode && !a.out_stats && !a.pool2;
   // forward GroupNorm+SiLU launches: the prologue is a compile-time constant only for the 2-workgroup/CU shapes; at
   // the 128-VGPR cap of the others it made the compiler interleave the SiLU chains and spill (32->32@256^2 +res+stats
-  // 153 -> 184 us), so those keep the run-time prologue flag (but the compile-time formats)
+  // 153 -> 184 us), so those keep the run-time prologue flag (but the compile-time formats).  (tried: 3 workgroups/CU
+  // = 168 VGPRs for those launches, compile-time prologue + packed SiLU, no spills: 32->32 152 -> 146 us alone, but
+  // the training step got 1.5 % slower -- fewer resident waves overlap worse with the weight-gradient stream)
   constexpr int FPRO = PXF == 4 ? PTI_PRO_GN_SILU : -1;
   if constexpr (KS == 3) {   // the activated-input side output is a separate instantiation (3x3 only)
     if (a.act_out) {
