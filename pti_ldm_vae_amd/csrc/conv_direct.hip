@@ -136,7 +136,25 @@ __global__ __launch_bounds__(256) void direct_fewcout_kernel(DArgs a, int tiles_
 
   // ---- phase 1: partial dot products of every centre pixel of the halo'd tile ----
   const int ppi = 256 / NC;                         // pixels per iteration
-  for (int q0 = 0; q0 < C::NP; q0 += ppi) {
+  // the halo pixels are fetched LB iterations at a time: one global round trip per batch instead of one per
+  // iteration (32 channels: the whole 180-pixel halo is 3 iterations = one batch; the loop used to expose three
+  // serial ~2 us round trips per 128 outputs and ran 8x off its byte roofline)
+  constexpr int LB = 4;
+  for (int qb = 0; qb < C::NP; qb += LB * ppi) {
+  u32x4 rawb[LB];
+#pragma unroll
+  for (int b = 0; b < LB; ++b) {
+    const int q = qb + b * ppi + tid / NC;
+    const int hy = q / C::HW, hx = q - hy * C::HW;
+    const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+    rawb[b] = u32x4{0u, 0u, 0u, 0u};
+    if (q < C::NP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+      rawb[b] = *(const u32x4*)(X + ((size_t)(n * a.H + iy) * a.W + ix) * a.Cin + lc * 8);
+  }
+#pragma unroll
+  for (int b = 0; b < LB; ++b) {
+    const int q0 = qb + b * ppi;
+    if (q0 >= C::NP) break;
     const int q = q0 + tid / NC;
     const int hy = q / C::HW, hx = q - hy * C::HW;
     const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
@@ -145,8 +163,7 @@ __global__ __launch_bounds__(256) void direct_fewcout_kernel(DArgs a, int tiles_
 #pragma unroll
     for (int j = 0; j < 8; ++j) f[j] = 0.f;
     if (ok) {
-      const u32x4 raw = *(const u32x4*)(X + ((size_t)(n * a.H + iy) * a.W + ix) * a.Cin + lc * 8);
-      unpack8f(raw, f, a.wide_f16);
+      unpack8f(rawb[b], f, a.wide_f16);
       if (a.prologue) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -214,6 +231,7 @@ __global__ __launch_bounds__(256) void direct_fewcout_kernel(DArgs a, int tiles_
           if (first + i < C::NV) P[q * C::NV + first + i] = v[i];
       }
     }
+  }
   }
   __syncthreads();
   // ---- phase 2: gather ----
