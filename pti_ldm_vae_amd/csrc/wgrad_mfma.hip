@@ -290,10 +290,14 @@ struct W3Cfg {
   static constexpr int LDS_BYTES = A_BYTES + D_BYTES;
 };
 
-template <int COB>
-__global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(COB == 1 ? 3 : 2, COB == 1 ? 3 : 2)))
-void wgrad_mfma3_kernel(WgArgs a) {   // COB 1: 3 waves/SIMD (<= 168 VGPR+AGPR); COB 2: 2 waves/SIMD
+// PLAIN: x is an already activated bf16 tensor (no prologue, no fp16 conversion) -- the training step's case: the
+// loader is a plain copy, the 16 scale/shift registers and the conversion code are compiled out.
+template <int COB, bool PLAIN>
+__global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(COB == 1 ? (PLAIN ? 4 : 3) : 2, COB == 1 ? (PLAIN ? 4 : 3) : 2)))
+void wgrad_mfma3_kernel(WgArgs a) {   // COB 1: 3 waves/SIMD (<= 168 VGPR+AGPR), 4 when PLAIN; COB 2: 2 waves/SIMD
   using C = W3Cfg<COB>;
+  const int prologue = PLAIN ? PTI_PRO_NONE : a.prologue;
+  const bool x_f16 = PLAIN ? false : (bool)a.x_f16;
   typedef short v4s __attribute__((ext_vector_type(4)));
   typedef short v8s __attribute__((ext_vector_type(8)));
   __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS_BYTES];
@@ -372,7 +376,7 @@ void wgrad_mfma3_kernel(WgArgs a) {   // COB 1: 3 waves/SIMD (<= 168 VGPR+AGPR);
     return n;
   };
   auto commit = [&](int n) {
-    if (a.prologue != PTI_PRO_NONE && n != cur_n) {
+    if (prologue != PTI_PRO_NONE && n != cur_n) {
       cur_n = n;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -390,17 +394,17 @@ void wgrad_mfma3_kernel(WgArgs a) {   // COB 1: 3 waves/SIMD (<= 168 VGPR+AGPR);
       const int p = lp + it * PSTEP;
       if (p < C::NP) {
         u32x4 r = araw[it];
-        if (a.prologue != PTI_PRO_NONE && ((aokm >> it) & 1u)) {
+        if (prologue != PTI_PRO_NONE && ((aokm >> it) & 1u)) {
           float f[8];
-          unpack8f(r, f, a.x_f16);
+          unpack8f(r, f, x_f16);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             float v = f[j] * sc[j] + sh[j];
-            if (a.prologue == PTI_PRO_GN_SILU) v = silu_f(v);
+            if (prologue == PTI_PRO_GN_SILU) v = silu_f(v);
             f[j] = v;
           }
           r = pack8(f);
-        } else if (a.x_f16) {
+        } else if (x_f16) {
           float f[8];
           unpack8f(r, f, true);
           r = pack8(f);
@@ -598,7 +602,12 @@ extern "C" int pti_conv_wgrad_mfma_partials(const void* x, const void* dy, const
   // v3: three waves per workgroup; 768 workgroups = 3 per CU measured best (512 .. 2048 within +-8 %: fewer
   // workgroups mean fewer 37-KB partial slabs to write and reduce, more mean more loads in flight); with two co
   // blocks (2 waves/SIMD) 512 = 2 per CU (768 / 1024: +25 %, 384: +17 %)
-  int S = (v3 ? (cob == 2 ? 512 : 768) : 512) / tiles_cc;
+  // plain (already activated bf16) inputs with at least two (co, ci) blocks: the loader-free instantiation fits 128
+  // VGPRs = 4 waves/SIMD, and with 1280 workgroups (5 per CU) more tiles are in flight per CU -- the kernel is bound by
+  // load latency x bytes in flight: 64->64@128^2 70.3 -> 64.2 us, 128->128@64^2 70.5 -> 62.7 us, nearest-2x 64->64 231
+  // -> 202 us.  The single-block 32->32 shape ran 15 % slower that way (83 -> 96 us) and keeps 3 waves/SIMD.
+  const bool plain = d->prologue == PTI_PRO_NONE && !d->in_f16 && cob == 1 && tiles_cc >= 2;
+  int S = (v3 ? (cob == 2 ? 512 : (plain ? 1280 : 768)) : 512) / tiles_cc;
   if (S > a.ntiles / 4) S = a.ntiles / 4;
   if (S > (v3 ? 512 : 256)) S = v3 ? 512 : 256;
   if (S < 1) S = 1;
@@ -607,8 +616,9 @@ extern "C" int pti_conv_wgrad_mfma_partials(const void* x, const void* dy, const
   if (v3 && S >= 8) S &= ~7;   // whole rounds over the 8 XCDs (see the block-order note in the kernel)
   a.S = S;
   hipStream_t st = (hipStream_t)s;
-  if (v3 && cob == 2) hipLaunchKernelGGL(wgrad_mfma3_kernel<2>, dim3(tiles_cc * S), dim3(192), 0, st, a);
-  else if (v3) hipLaunchKernelGGL(wgrad_mfma3_kernel<1>, dim3(tiles_cc * S), dim3(192), 0, st, a);
+  if (v3 && cob == 2) hipLaunchKernelGGL((wgrad_mfma3_kernel<2, false>), dim3(tiles_cc * S), dim3(192), 0, st, a);
+  else if (v3 && plain) hipLaunchKernelGGL((wgrad_mfma3_kernel<1, true>), dim3(tiles_cc * S), dim3(192), 0, st, a);
+  else if (v3) hipLaunchKernelGGL((wgrad_mfma3_kernel<1, false>), dim3(tiles_cc * S), dim3(192), 0, st, a);
   else if (d->ksize == 1) launch_wt<1, 1>(a, co_t, ci_t, tiles_cc, st);
   else launch_wt<3, 2>(a, co_t, ci_t, tiles_cc, st);
   PTI_CHECK_LAUNCH("conv_wgrad_mfma");

@@ -306,17 +306,18 @@ def conv_wgrad_mfma(x, dy, dw, dbias, *, ksize=3, mode=PTI_CONV_S1, prologue=PTI
                                           _stream()), "pti_conv_wgrad_reduce")
     flops = 2.0 * n * ho * wo * cout * cin * ksize * ksize
     # algorithmic bytes: x and dy read once (bf16); dw itself is negligible (the split-K slabs are not algorithmic)
-    prof.append((_wgrad_kernel_name(ksize, mode, cin, cout, n * ((ho + 7) // 8) * ((wo + 15) // 16), prologue), flops,
+    prof.append((_wgrad_kernel_name(ksize, mode, cin, cout, n * ((ho + 7) // 8) * ((wo + 15) // 16), prologue, x.dtype == F16), flops,
                  2.0 * (x.numel() + dy.numel()), e0, e1))
     return dw
 
 
-def _wgrad_kernel_name(ksize, mode, cin, cout, ntiles, prologue=PTI_PRO_NONE):
+def _wgrad_kernel_name(ksize, mode, cin, cout, ntiles, prologue=PTI_PRO_NONE, x_f16=False):
     """Kernel symbol pti_conv_wgrad_mfma picks (mirrors its tile choice), as rocprof names it."""
     if ksize == 3 and mode != PTI_CONV_S2PAD:
         env = os.environ.get("PTI_WGRAD_COB")
         cob = 2 if (cout % 64 == 0 and mode == PTI_CONV_S1 and env != "1" and (env == "2" or prologue != PTI_PRO_NONE)) else 1
-        return f"wgrad_mfma3_kernel<{cob}>"
+        plain = prologue == PTI_PRO_NONE and not x_f16 and cob == 1 and (cout // 32) * (cin // 32) >= 2
+        return f"wgrad_mfma3_kernel<{cob}, {str(plain).lower()}>"
     co_t, ci_t = (64 if cout % 64 == 0 else 32), (64 if cin % 64 == 0 else 32)
     if ntiles * (cout // co_t) * (cin // ci_t) < 16 * 512:
         co_t = ci_t = 32

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Bitwise run-to-run reproducibility of individual kernels on fixed inputs (statistics excepted: float atomics).
+"""Bitwise run-to-run reproducibility of individual kernels on fixed inputs (statistics are integer fixed-point sums, every other reduction stores per-workgroup partials: all outputs compared).
 A kernel whose OUTPUT TENSOR differs between two launches on identical inputs has a race."""
 import os
 import sys
