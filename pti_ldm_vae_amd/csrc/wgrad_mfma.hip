@@ -602,14 +602,15 @@ extern "C" int pti_conv_wgrad_mfma_partials(const void* x, const void* dy, const
   // v3: three waves per workgroup; 768 workgroups = 3 per CU measured best (512 .. 2048 within +-8 %: fewer
   // workgroups mean fewer 37-KB partial slabs to write and reduce, more mean more loads in flight); with two co
   // blocks (2 waves/SIMD) 512 = 2 per CU (768 / 1024: +25 %, 384: +17 %)
-  // plain (already activated bf16) inputs with at least two (co, ci) blocks: the loader-free instantiation fits 128
+  // plain (already activated bf16) inputs: the loader-free instantiation fits 128
   // VGPRs = 4 waves/SIMD, and with 1280 workgroups (5 per CU) more tiles are in flight per CU -- the kernel is bound by
   // load latency x bytes in flight: 64->64@128^2 70.3 -> 64.2 us, 128->128@64^2 70.5 -> 62.7 us, nearest-2x 64->64 231
-  // -> 202 us.  The single-block 32->32 shape ran 15 % slower that way (83 -> 96 us) and keeps 3 waves/SIMD.
-  const bool plain = d->prologue == PTI_PRO_NONE && !d->in_f16 && cob == 1 && tiles_cc >= 2;
-  int S = (v3 ? (cob == 2 ? 512 : (plain ? 1280 : 768)) : 512) / tiles_cc;
+  // -> 202 us; the single-block 32->32@256^2 shape 89.0 -> 82.5 us with 1024 workgroups (768: 83.3, 1152: 83.9).
+  const bool plain = d->prologue == PTI_PRO_NONE && !d->in_f16 && cob == 1;
+  int S = (v3 ? (cob == 2 ? 512 : (plain ? (tiles_cc == 1 ? 1024 : 1280) : 768)) : 512) / tiles_cc;
   if (S > a.ntiles / 4) S = a.ntiles / 4;
-  if (S > (v3 ? 512 : 256)) S = v3 ? 512 : 256;
+  const int scap = v3 ? (plain ? 1024 : 512) : 256;
+  if (S > scap) S = scap;
   if (S < 1) S = 1;
   if (S > smax) S = (int)smax;
   if (S < 1) PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma: workspace too small (%lld bytes per split needed)", a.slab_stride * 4);
