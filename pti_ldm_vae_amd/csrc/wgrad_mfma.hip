@@ -290,14 +290,15 @@ struct W3Cfg {
   static constexpr int LDS_BYTES = A_BYTES + D_BYTES;
 };
 
-// PLAIN: x is an already activated bf16 tensor (no prologue, no fp16 conversion) -- the training step's case: the
-// loader is a plain copy, the 16 scale/shift registers and the conversion code are compiled out.
+// PLAIN: no GroupNorm prologue -- the training step's case (x is the saved, already activated bf16 tensor, or the
+// fp16 stream tensor of an up-sampling conv: the loader is a copy / a format conversion); the 16 scale/shift registers
+// and the normalisation code are compiled out and the kernel fits 128 VGPRs.
 template <int COB, bool PLAIN>
 __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(COB == 1 ? (PLAIN ? 4 : 3) : 2, COB == 1 ? (PLAIN ? 4 : 3) : 2)))
 void wgrad_mfma3_kernel(WgArgs a) {   // COB 1: 3 waves/SIMD (<= 168 VGPR+AGPR), 4 when PLAIN; COB 2: 2 waves/SIMD
   using C = W3Cfg<COB>;
   const int prologue = PLAIN ? PTI_PRO_NONE : a.prologue;
-  const bool x_f16 = PLAIN ? false : (bool)a.x_f16;
+  const bool x_f16 = (bool)a.x_f16;
   typedef short v4s __attribute__((ext_vector_type(4)));
   typedef short v8s __attribute__((ext_vector_type(8)));
   __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS_BYTES];
@@ -602,11 +603,11 @@ extern "C" int pti_conv_wgrad_mfma_partials(const void* x, const void* dy, const
   // v3: three waves per workgroup; 768 workgroups = 3 per CU measured best (512 .. 2048 within +-8 %: fewer
   // workgroups mean fewer 37-KB partial slabs to write and reduce, more mean more loads in flight); with two co
   // blocks (2 waves/SIMD) 512 = 2 per CU (768 / 1024: +25 %, 384: +17 %)
-  // plain (already activated bf16) inputs: the loader-free instantiation fits 128
+  // inputs without a prologue: the loader-free instantiation fits 128
   // VGPRs = 4 waves/SIMD, and with 1280 workgroups (5 per CU) more tiles are in flight per CU -- the kernel is bound by
   // load latency x bytes in flight: 64->64@128^2 70.3 -> 64.2 us, 128->128@64^2 70.5 -> 62.7 us, nearest-2x 64->64 231
   // -> 202 us; the single-block 32->32@256^2 shape 89.0 -> 82.5 us with 1024 workgroups (768: 83.3, 1152: 83.9).
-  const bool plain = d->prologue == PTI_PRO_NONE && !d->in_f16 && cob == 1;
+  const bool plain = d->prologue == PTI_PRO_NONE && cob == 1;
   int S = (v3 ? (cob == 2 ? 512 : (plain ? (tiles_cc == 1 ? 1024 : 1280) : 768)) : 512) / tiles_cc;
   if (S > a.ntiles / 4) S = a.ntiles / 4;
   const int scap = v3 ? (plain ? 1024 : 512) : 256;

@@ -316,7 +316,7 @@ def _wgrad_kernel_name(ksize, mode, cin, cout, ntiles, prologue=PTI_PRO_NONE, x_
     if ksize == 3 and mode != PTI_CONV_S2PAD:
         env = os.environ.get("PTI_WGRAD_COB")
         cob = 2 if (cout % 64 == 0 and mode == PTI_CONV_S1 and env != "1" and (env == "2" or prologue != PTI_PRO_NONE)) else 1
-        plain = prologue == PTI_PRO_NONE and not x_f16 and cob == 1
+        plain = prologue == PTI_PRO_NONE and cob == 1
         return f"wgrad_mfma3_kernel<{cob}, {str(plain).lower()}>"
     co_t, ci_t = (64 if cout % 64 == 0 else 32), (64 if cin % 64 == 0 else 32)
     if ntiles * (cout // co_t) * (cin // ci_t) < 16 * 512:
