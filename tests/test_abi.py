@@ -64,3 +64,27 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.PtiError, match="no CPU/PyTorch fallback"):
         _lib.lib()
+
+
+def test_workspace_size_constants_match_header():
+    """ops sizes the scratch of the fixed-order reductions from the header's block caps."""
+    from pti_ldm_vae_amd import ops
+    text = open(os.path.join(ROOT, "include", "pti_vae.h")).read()
+    caps = {k: int(v) for k, v in re.findall(r"#define (PTI_[A-Z_]+_MAX_BLOCKS) (\d+)", text)}
+    assert caps == {"PTI_POST_QUANT_BWD_MAX_BLOCKS": ops.POST_QUANT_BWD_MAX_BLOCKS,
+                    "PTI_LATENT_BWD_MAX_BLOCKS": ops.LATENT_BWD_MAX_BLOCKS,
+                    "PTI_VAE_LOSS_MAX_BLOCKS": ops.VAE_LOSS_MAX_BLOCKS}
+
+
+def test_tile_and_block_queries_need_no_gpu():
+    """pti_conv_gnbwd_tiles / pti_gn_bwd_blocks are pure host arithmetic: callable on a CPU-only box."""
+    from pti_ldm_vae_amd import _lib as L
+    lib = L.lib()
+    d = L.ConvDesc(n=2, h=64, w=48, cin=64, ho=64, wo=48, cout=32, ksize=3, mode=L.PTI_CONV_S1, groups=16, eps=1e-6)
+    assert lib.pti_conv_gnbwd_tiles(C.byref(d)) == (64 // 16) * (48 // 16)      # 32-channel tile: 16 x 16 pixels
+    d.cout = 128
+    assert lib.pti_conv_gnbwd_tiles(C.byref(d)) == (64 // 8) * (48 // 16)       # 128-channel tile: 8 x 16 pixels
+    d.cout = 48
+    assert lib.pti_conv_gnbwd_tiles(C.byref(d)) == 0                            # not a multiple of 32: unsupported
+    assert lib.pti_gn_bwd_blocks(2, 64 * 64, 64) >= 1
+    assert lib.pti_gn_bwd_blocks(2, 64 * 64, 1024) == 0                         # above the kernel's channel cap

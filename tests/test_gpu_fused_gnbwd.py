@@ -45,3 +45,24 @@ def test_dgrad_with_fused_gn_backward(dev, n, cin, cout, h, w, ks, silu, res):
     _report("fused gnbwd dx", dx.float().cpu().permute(0, 3, 1, 2), ref_dx, max_frac=1.5e-2, l2=6e-3)
     _report("fused gnbwd dgamma", dg, gamma.grad, max_frac=1e-2, l2=5e-3)
     _report("fused gnbwd dbeta", db, beta.grad, max_frac=1e-2, l2=5e-3)
+
+
+@pytest.mark.parametrize("n,tiles,row", [(3, 1, 64), (2, 37, 128), (4, 512, 64), (1, 100, 24)])
+def test_gn_sums_finalize_adds_tile_rows_in_a_fixed_order(dev, n, tiles, row):
+    """pti_gn_sums_finalize: sums[n][i] = sum over tiles of partials[n][t][i]; equal to an fp64 sum within fp32
+    rounding, identical bits on every call, rows not a multiple of 64 handled."""
+    import ctypes as C
+    from pti_ldm_vae_amd import _lib as L
+    torch.manual_seed(5)
+    part = torch.randn(n, tiles, row, device=dev)
+    outs = []
+    for _ in range(3):
+        sums = torch.full((n, row), float("nan"), device=dev)
+        L.check(L.lib().pti_gn_sums_finalize(C.c_void_p(part.data_ptr()), C.c_void_p(sums.data_ptr()), n, tiles, row,
+                                             C.c_void_p(torch.cuda.current_stream().cuda_stream)), "pti_gn_sums_finalize")
+        outs.append(sums)
+    torch.cuda.synchronize()
+    ref = part.double().sum(dim=1)
+    err = (outs[0].double() - ref).abs().max().item()
+    assert err <= 1e-6 * tiles ** 0.5 * 8 + 1e-6, err
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
