@@ -701,16 +701,7 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
     for (int q = 0; q < 4; ++q) {
       const int col = col0 + 8 * q, ch0 = ct * CT + col;
       float scv[4], shv[4], muv[4], rsv[4], l1[4] = {0.f, 0.f, 0.f, 0.f}, l2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int g = (ch0 + r) / gcpg;
-        const float sum = sfl[2 * g], sq = sfl[2 * g + 1];
-        const float mean = sum * a.g_inv_cnt;
-        const float rstd = rsqrtf(fmaxf(sq * a.g_inv_cnt - mean * mean, 0.f) + a.g_eps);
-        muv[r] = mean; rsv[r] = rstd;
-        scv[r] = rstd * a.g_gamma[ch0 + r];
-        shv[r] = a.g_beta[ch0 + r] - mean * scv[r];
-      }
+      gn_params<4>(sfl, a.g_gamma, a.g_beta, ch0, gcpg, a.g_inv_cnt, a.g_eps, scv, shv, muv, rsv);
 #pragma unroll
       for (int i = 0; i < PXF; ++i) {
         const int p = (2 * PXF * wm + 2 * i + (j >> 4)) * 16 + (j & 15);

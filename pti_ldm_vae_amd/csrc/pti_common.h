@@ -130,6 +130,53 @@ __device__ __forceinline__ float dsilu_f(float v) {
   return s * (1.0f + v * (1.0f - s));
 }
 
+// GroupNorm scale / shift / mean / rstd of NCH consecutive channels ch0 .. ch0+NCH-1 (ch0 % NCH == 0) from the float
+// {sum, sum of squares} table `sfl` of this sample.  For power-of-two group sizes (every reference config) the group
+// index is a shift and the per-group work -- table read, mean, v_rsq_f32 -- is done once per GROUP on a straight-line
+// path per group size; an integer division by a run-time value (~25 VALU instructions) and the denormal-guarded
+// rsqrtf per CHANNEL cost the fused GroupNorm-backward epilogue ~500 VALU instructions per thread and tile.
+template <int NCH, int GS>
+__device__ __forceinline__ void gn_params_groups(const float* sfl, const float* __restrict__ gamma,
+                                                 const float* __restrict__ beta, int ch0, int g0, float inv_cnt, float eps,
+                                                 float* sc, float* sh, float* mu, float* rs) {
+#pragma unroll
+  for (int k = 0; k < NCH / GS; ++k) {
+    const f32x2 st = *(const f32x2*)(sfl + 2 * (g0 + k));
+    const float mean = st[0] * inv_cnt;
+    const float rstd = __builtin_amdgcn_rsqf(fmaxf(st[1] * inv_cnt - mean * mean, 0.f) + eps);   // var + eps >= eps: no denormals
+#pragma unroll
+    for (int jj = 0; jj < GS; ++jj) {
+      const int j = k * GS + jj;
+      sc[j] = rstd * gamma[ch0 + j];
+      sh[j] = beta[ch0 + j] - mean * sc[j];
+      mu[j] = mean;
+      rs[j] = rstd;
+    }
+  }
+}
+template <int NCH>
+__device__ __forceinline__ void gn_params(const float* sfl, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                          int ch0, int cpg, float inv_cnt, float eps, float* sc, float* sh, float* mu,
+                                          float* rs) {
+  if ((cpg & (cpg - 1)) == 0) {   // wave-uniform
+    const int g0 = ch0 >> __builtin_ctz(cpg);
+    if (cpg >= NCH) gn_params_groups<NCH, NCH>(sfl, gamma, beta, ch0, g0, inv_cnt, eps, sc, sh, mu, rs);
+    else if (cpg == 2) gn_params_groups<NCH, 2>(sfl, gamma, beta, ch0, g0, inv_cnt, eps, sc, sh, mu, rs);
+    else gn_params_groups<NCH, 1>(sfl, gamma, beta, ch0, g0, inv_cnt, eps, sc, sh, mu, rs);
+  } else {
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int g = (ch0 + j) / cpg;
+      const float mean = sfl[2 * g] * inv_cnt;
+      const float rstd = __builtin_amdgcn_rsqf(fmaxf(sfl[2 * g + 1] * inv_cnt - mean * mean, 0.f) + eps);
+      sc[j] = rstd * gamma[ch0 + j];
+      sh[j] = beta[ch0 + j] - mean * sc[j];
+      mu[j] = mean;
+      rs[j] = rstd;
+    }
+  }
+}
+
 // SiLU(x * sc + sh) of two elements with the packed-fp32 VALU ops (v_pk_fma / v_pk_mul / v_pk_add: two lanes-worth per
 // issue) around the two transcendentals each element needs (v_exp_f32, v_rcp_f32): 4 packed + 4 scalar issues per
 // PAIR instead of 6 scalar issues per element.  The narrow-layer convs are VALU-bound in their GroupNorm+SiLU loader.
