@@ -48,9 +48,12 @@ struct WCfg {
   static constexpr int LDS_BYTES = (A_BYTES + D_BYTES) > RED_BYTES ? (A_BYTES + D_BYTES) : RED_BYTES;
 };
 
-template <int KS, int S_, int CO_T, int CI_T>
+// PLAIN: no GroupNorm prologue (every launch of the training step that takes this kernel): its code and the 16
+// scale/shift registers are compiled out
+template <int KS, int S_, int CO_T, int CI_T, bool PLAIN>
 __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgArgs a) {
   using C = WCfg<KS, S_, CO_T, CI_T>;
+  const int prologue = PLAIN ? PTI_PRO_NONE : a.prologue;
   typedef short v4s __attribute__((ext_vector_type(4)));
   __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS_BYTES];
   unsigned char* lA = smem;
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgArgs a) {
   };
 
   auto write_lds = [&](int n) {
-    if (a.prologue != PTI_PRO_NONE && n != cur_n) {
+    if (prologue != PTI_PRO_NONE && n != cur_n) {
       cur_n = n;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -142,13 +145,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgArgs a) {
       const int p = alp + it * APSTEP;
       if (p < C::NP) {
         u32x4 r = araw[it];
-        if (a.prologue != PTI_PRO_NONE && aok[it]) {
+        if (prologue != PTI_PRO_NONE && aok[it]) {
           float f[8];
           unpack8f(r, f, a.x_f16);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             float v = f[j] * sc[j] + sh[j];
-            if (a.prologue == PTI_PRO_GN_SILU) v = silu_f(v);
+            if (prologue == PTI_PRO_GN_SILU) v = silu_f(v);
             f[j] = v;
           }
           r = pack8(f);
@@ -541,7 +544,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 template <int KS, int S_, int CO_T, int CI_T>
 void launch_w(const WgArgs& a, int grid_y, hipStream_t st) {
-  hipLaunchKernelGGL((wgrad_mfma_kernel<KS, S_, CO_T, CI_T>), dim3(grid_y, a.S), dim3(256), 0, st, a);
+  if (a.prologue == PTI_PRO_NONE)
+    hipLaunchKernelGGL((wgrad_mfma_kernel<KS, S_, CO_T, CI_T, true>), dim3(grid_y, a.S), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((wgrad_mfma_kernel<KS, S_, CO_T, CI_T, false>), dim3(grid_y, a.S), dim3(256), 0, st, a);
 }
 template <int KS, int S_>
 void launch_wt(const WgArgs& a, int co_t, int ci_t, int grid_y, hipStream_t st) {

@@ -321,7 +321,8 @@ def _wgrad_kernel_name(ksize, mode, cin, cout, ntiles, prologue=PTI_PRO_NONE, x_
     co_t, ci_t = (64 if cout % 64 == 0 else 32), (64 if cin % 64 == 0 else 32)
     if ntiles * (cout // co_t) * (cin // ci_t) < 16 * 512:
         co_t = ci_t = 32
-    return f"wgrad_mfma_kernel<{ksize}, {2 if mode == PTI_CONV_S2PAD else 1}, {co_t}, {ci_t}>"
+    return (f"wgrad_mfma_kernel<{ksize}, {2 if mode == PTI_CONV_S2PAD else 1}, {co_t}, {ci_t}, "
+            f"{str(prologue == PTI_PRO_NONE).lower()}>")
 
 
 def gn_bwd(x, da, dx, stats, gamma, beta, sums, dgamma, dbeta, *, groups, eps=1e-6, silu=True, dres=None):
