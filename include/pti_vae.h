@@ -13,8 +13,9 @@
  *   - never allocates, never synchronises, never throws;
  *   - returns 0 on success or a negative PTI_E* code; pti_last_error_string() explains it;
  *   - activations are NHWC bf16 (channels innermost) unless a parameter says otherwise;
- *   - "stats" buffers are float[N][G][2] = {sum, sum of squares} over one (sample, group);
- *     consumers turn them into mean / rstd themselves (count and eps are passed along).
+ *   - "stats" buffers are int64_t[N][G][2] = Q47.16 fixed-point {sum, sum of squares} over one
+ *     (sample, group) -- see the note above pti_conv_desc; consumers turn them into mean / rstd
+ *     themselves (count and eps are passed along).
  */
 #ifndef PTI_VAE_H
 #define PTI_VAE_H
@@ -27,7 +28,7 @@ extern "C" {
 
 typedef void* pti_stream_t; /* hipStream_t */
 
-#define PTI_ABI_VERSION 1
+#define PTI_ABI_VERSION 2
 
 #define PTI_OK 0
 #define PTI_EINVAL (-1)   /* bad pointer / dimension */
@@ -71,6 +72,10 @@ typedef struct pti_conv_desc {
   /* pti_conv2d_mfma only: y is [n][ho/2][wo/2][cout] = the 2x2 SUM pool of the conv output (the data      */
   /* gradient of nn.Upsample(nearest, 2x) + conv, fused: the full-resolution gradient is never written).   */
   int32_t pool2x2_out;
+  /* pti_conv2d_mfma / _saveact only: w_packed was packed with w_f16 = 1 and the MFMA multiplies fp16 operands      */
+  /* (v_mfma_f32_32x32x16_f16; same rate as bf16, 8x finer operand rounding).  Needs in_f16 = out_f16 = 1 (and      */
+  /* res_f16 when a residual is added): the forward convs on fp16 storage.  Gradients always use bf16 operands.     */
+  int32_t w_f16;
 } pti_conv_desc;
 
 int pti_abi_version(void);
@@ -84,7 +89,7 @@ int64_t pti_conv_packed_bytes(int cout, int cin, int ksize, int mode);
  * W'[ci][co][2-kh][2-kw]; cout/cin are those of the ORIGINAL weight.  nsrc>1 concatenates
  * nsrc weights along the output channels (to_q/to_k/to_v fused into one 1x1).             */
 int pti_conv_pack_weights(const float* const* w_oihw, int nsrc, void* packed, int cout, int cin,
-                          int ksize, int mode, int transpose_flip, pti_stream_t s);
+                          int ksize, int mode, int transpose_flip, int w_f16, pti_stream_t s);
 
 /* Batched form (one launch for all layers of the model after an optimiser step): the caller keeps a
  * table of pti_conv_pack_entry_bytes()-byte entries; pti_conv_pack_table_fill writes ONE entry into HOST
@@ -92,7 +97,7 @@ int pti_conv_pack_weights(const float* const* w_oihw, int nsrc, void* packed, in
  * first-block index of every entry, then launches everything with pti_conv_pack_weights_batched.   */
 int pti_conv_pack_entry_bytes(void);
 int pti_conv_pack_table_fill(void* host_entry, const float* w_oihw_dev, void* packed_dev, int cout,
-                             int cin, int ksize, int mode, int transpose_flip, int64_t* nblocks);
+                             int cin, int ksize, int mode, int transpose_flip, int w_f16, int64_t* nblocks);
 int pti_conv_pack_weights_batched(const void* table_dev, const int* blk_first_dev, int n,
                                   int total_blocks, pti_stream_t s);
 
@@ -105,7 +110,8 @@ int pti_gn_stats(const void* x_nhwc_16bit, int64_t* stats, int n, int hw, int c,
 /* Implicit-GEMM 3x3 / 1x1 convolution on bf16 MFMA (v_mfma_f32_32x32x16_bf16), fp32 accumulate:
  * y = conv(prologue(x)) + bias [+ residual].  Replaces nn.Conv2d (+ the GroupNorm/SiLU in
  * front of it, + the residual add behind it) inside MONAI AEKLResBlock / AEKLDownsample /
- * Upsample / SABlock linears.  cin, cout multiples of 32.  in_stats: float[n][groups][2].  */
+ * Upsample / SABlock linears.  cin, cout multiples of 32.  in_stats / out_stats: int64_t[n][groups][2]
+ * Q47.16 fixed-point sums (above).                                                          */
 int pti_conv2d_mfma(const void* x, const void* w_packed, const float* bias, const int64_t* in_stats,
                     const float* gamma, const float* beta, const void* residual, void* y,
                     int64_t* out_stats, const pti_conv_desc* d, pti_stream_t s);

@@ -11,6 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PTI_VAE_LIB") or os.path.join(_HERE, "libpti_vae_hip.so")   # env: kernel-variant A/B runs
 
+ABI_VERSION = 2   # PTI_ABI_VERSION of include/pti_vae.h
 PTI_CONV_S1, PTI_CONV_S2PAD, PTI_CONV_UP2, PTI_CONV_ZINS = 0, 1, 2, 3
 PTI_PRO_NONE, PTI_PRO_GN, PTI_PRO_GN_SILU = 0, 1, 2
 
@@ -26,6 +27,7 @@ class ConvDesc(C.Structure):
         ("eps", C.c_float), ("in_f32", C.c_int32), ("out_f32", C.c_int32),
         ("in_stride", C.c_int64 * 4), ("out_stride", C.c_int64 * 4),
         ("in_f16", C.c_int32), ("res_f16", C.c_int32), ("out_f16", C.c_int32), ("pool2x2_out", C.c_int32),
+        ("w_f16", C.c_int32),
     ]
 
 
@@ -40,9 +42,9 @@ SIGNATURES = {
     "pti_abi_version": (_I, []),
     "pti_last_error_string": (C.c_char_p, []),
     "pti_conv_packed_bytes": (_I64, [_I, _I, _I, _I]),
-    "pti_conv_pack_weights": (_I, [C.POINTER(_P), _I, _P, _I, _I, _I, _I, _I, _P]),
+    "pti_conv_pack_weights": (_I, [C.POINTER(_P), _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "pti_conv_pack_entry_bytes": (_I, []),
-    "pti_conv_pack_table_fill": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, C.POINTER(_I64)]),
+    "pti_conv_pack_table_fill": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, C.POINTER(_I64)]),
     "pti_conv_pack_weights_batched": (_I, [_P, _P, _I, _I, _P]),
     "pti_gn_stats": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "pti_conv2d_mfma": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(ConvDesc), _P]),
@@ -99,8 +101,8 @@ def lib() -> C.CDLL:
             fn.restype = res
             fn.argtypes = args
         ver = handle.pti_abi_version()
-        if ver != 1:
-            raise PtiError(f"libpti_vae_hip.so ABI version {ver}, expected 1")
+        if ver != ABI_VERSION:
+            raise PtiError(f"libpti_vae_hip.so ABI version {ver}, expected {ABI_VERSION}")
         _lib = handle
     return _lib
 

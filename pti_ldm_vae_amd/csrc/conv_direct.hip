@@ -38,6 +38,7 @@ __device__ __forceinline__ void st_narrow(void* p, long long idx, int f32, float
 // ---- few input channels -> many output channels (cout % 32 == 0, output NHWC bf16 dense) ----
 // thread = (pixel, 32-cout block = blockIdx.y); weights are block-uniform (scalar loads).
 __global__ __launch_bounds__(256) void direct_fewcin_kernel(DArgs a) {
+  if (a.wide_f16) fp16_saturate_on();   // wave-uniform: fp16 output saturates instead of overflowing to inf
   const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long npix = (long long)a.N * a.H * a.W;
   if (pix >= npix) return;

@@ -85,10 +85,22 @@ struct ConvArgs {
   // 16-bit storage format of x / residual (or the GN input of the fused backward) / y: 0 = bf16, 1 = fp16
   int in_f16, res_f16, out_f16;
   int pool2;   // v2 kernel: store the 2x2-sum-pooled output tile [N][Ho/2][Wo/2][Cout] (data gradient of nearest-2x up-sampling)
+  int w_f16;   // packed weights are IEEE fp16 and the MFMA runs v_mfma_f32_32x32x16_f16 on fp16 operands (forward convs on fp16 storage)
 };
 
-template <int KS, int S, int CK, int COUT_TILE>
+// One 32x32x16 MFMA step on bf16 or (OPH) fp16 operands; the fragment registers are typed bf16x8 either way.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <bool OPH>
+__device__ __forceinline__ f32x16 mfma32(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+  if constexpr (OPH)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+template <int KS, int S, int CK, int COUT_TILE, bool OPH>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
+  if (a.out_f16) fp16_saturate_on();   // wave-uniform (kernel argument)
   using C = Cfg<KS, S, CK, COUT_TILE>;
   __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS_BYTES];
   unsigned char* halo = smem;
@@ -214,8 +226,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
             if (a.prologue == PTI_PRO_GN_SILU) v = silu_f(v);
             f[j] = v;
           }
-          r = pack8(f);
-        } else if (a.in_f16) {   // no prologue: the MFMA operand is bf16, convert the fp16 piece
+          r = OPH ? pack8f(f, true) : pack8(f);
+        } else if (a.in_f16 && !OPH) {   // no prologue: the MFMA operand is bf16, convert the fp16 piece
           float f[8];
           unpack8f(r, f, true);
           r = pack8(f);
@@ -251,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
         for (int i = 0; i < C::PXF; ++i)
 #pragma unroll
           for (int c = 0; c < C::CF; ++c)
-            acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[c], bfrag[i], acc[i][c], 0, 0, 0);
+            acc[i][c] = mfma32<OPH>(afrag[c], bfrag[i], acc[i][c]);
       }
       if (more) wstore((g + 1) & 1);
       __syncthreads();
@@ -444,6 +456,11 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
   const bool in_f16 = FM == 0 ? (bool)a.in_f16 : (FM == 1);
   const bool res_f16 = FM == 0 ? (bool)a.res_f16 : (FM == 1 || FM == 3);
   const bool out_f16 = FM == 0 ? (bool)a.out_f16 : (FM == 1);
+  // FM == 1 (every operand tensor fp16: the forward convs of the default engine) multiplies fp16 operands
+  // (v_mfma_f32_32x32x16_f16, fp16-packed weights): same rate as bf16, 8x finer operand rounding, and the fp16
+  // activations need no conversion on their way into LDS.  Everything else (gradients) stays bf16.
+  constexpr bool OPH = (FM == 1);
+  if (out_f16) fp16_saturate_on();   // wave-uniform
   __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS_BYTES];
   unsigned char* halo = smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -595,8 +612,8 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
               f[j] = v;
             }
           }
-          r = pack8(f);
-        } else if (in_f16) {   // no prologue: the MFMA operand is bf16, convert the fp16 piece
+          r = OPH ? pack8f(f, true) : pack8(f);
+        } else if (in_f16 && !OPH) {   // no prologue: the MFMA operand is bf16, convert the fp16 piece
           float f[8];
           unpack8f(r, f, true);
           r = pack8(f);
@@ -622,8 +639,13 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
           const int vy = vy0 + hy, vx = vx0 + hx;
           if (vy < a.H && vx < a.W) {
             const int key = (hx >> C::KEY_SHIFT) & (C::NC - 1);
-            __builtin_nontemporal_store(*(const u32x4*)(halo + (hy * C::HW + hx) * C::PIXB + ((c8 ^ key) << 4)),
-                                        (u32x4*)(a.act_out + ((size_t)(n * a.H + vy) * a.W + vx) * a.Cin + chunk * CK + c8 * 8));
+            u32x4 piece = *(const u32x4*)(halo + (hy * C::HW + hx) * C::PIXB + ((c8 ^ key) << 4));
+            if constexpr (OPH) {   // the staged operand is fp16; the saved copy is the weight gradient's bf16 operand
+              float f[8];
+              unpack8f(piece, f, true);
+              piece = pack8(f);
+            }
+            __builtin_nontemporal_store(piece, (u32x4*)(a.act_out + ((size_t)(n * a.H + vy) * a.W + vx) * a.Cin + chunk * CK + c8 * 8));
           }
         }
       }
@@ -654,11 +676,11 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
         if ((u & 1) == 0) {
           bread(b1, kb0 + u + 1);
 #pragma unroll
-          for (int i = 0; i < PXF; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[u], b0[i], acc[i], 0, 0, 0);
+          for (int i = 0; i < PXF; ++i) acc[i] = mfma32<OPH>(w[u], b0[i], acc[i]);
         } else {
           bread(b0, kb0 + u + 1);
 #pragma unroll
-          for (int i = 0; i < PXF; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[u], b1[i], acc[i], 0, 0, 0);
+          for (int i = 0; i < PXF; ++i) acc[i] = mfma32<OPH>(w[u], b1[i], acc[i]);
         }
       }
       if (C::R & 1) {  // odd group length: the last read went to b1/b0 alternately; realign so b0 is current
@@ -870,7 +892,9 @@ int launch2_cfg(ConvArgs a, hipStream_t st) {
   a.g_T = a.tiles_x * a.tiles_y;
   dim3 grid(a.N * a.tiles_x * a.tiles_y, a.Cout / CT);
   const bool res = a.res != nullptr;
-  const int fm = (a.in_f16 && a.out_f16 && (a.res_f16 || !res)) ? 1
+  // mode 1 multiplies fp16 operands and needs the fp16 weight pack; fp16 storage with bf16-packed weights takes the
+  // run-time-flag instantiation (operands converted to bf16 in the loader)
+  const int fm = (a.w_f16 && a.in_f16 && a.out_f16 && (a.res_f16 || !res)) ? 1
                : (!a.in_f16 && !a.out_f16 && (!a.res_f16 || !res)) ? 2
                : (!a.in_f16 && !a.out_f16 && a.res_f16) ? 3 : 0;
   // compile-time specialisations the engine's launches hit (anything else: the run-time-flag instantiation)
@@ -924,6 +948,7 @@ struct PackArgs {
   int cout_l, cin_l;   // logical (as seen by the consuming conv) channel counts
   int cout_o, cin_o;   // original weight dims (per source)
   int ks, ck, cout_tile, flip;
+  int f16;   // store IEEE fp16 instead of bf16 (operands of the fp16 forward MFMA)
   long long total;
 };
 
@@ -953,10 +978,11 @@ __device__ __forceinline__ void pack_eight(const PackArgs& p, int e8) {
   float f[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) f[j] = src[j * stride];
-  *(u32x4*)(p.dst + (size_t)e8 * 8) = pack8(f);
+  *(u32x4*)(p.dst + (size_t)e8 * 8) = p.f16 ? pack8f(f, true) : pack8(f);
 }
 
 __global__ void pack_weights_kernel(PackArgs p) {
+  if (p.f16) fp16_saturate_on();
   const long long e8 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e8 * 8 < p.total) pack_eight(p, (int)e8);
 }
@@ -970,6 +996,7 @@ __global__ void pack_weights_batched_kernel(const PackArgs* __restrict__ table, 
     if (blk_first[mid] <= b) lo = mid; else hi = mid - 1;
   }
   const PackArgs p = table[lo];
+  if (p.f16) fp16_saturate_on();   // p is block-uniform
   const int e8 = (b - blk_first[lo]) * 256 + threadIdx.x;
   if ((long long)e8 * 8 < p.total) pack_eight(p, e8);
 }
@@ -977,7 +1004,8 @@ __global__ void pack_weights_batched_kernel(const PackArgs* __restrict__ table, 
 template <int KS, int S, int CK, int COUT_TILE>
 int launch_cfg(const ConvArgs& a, hipStream_t st) {
   dim3 grid(a.N * a.tiles_x * a.tiles_y, a.Cout / COUT_TILE);
-  hipLaunchKernelGGL((conv_mfma_kernel<KS, S, CK, COUT_TILE>), grid, dim3(256), 0, st, a);
+  if (a.w_f16) hipLaunchKernelGGL((conv_mfma_kernel<KS, S, CK, COUT_TILE, true>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((conv_mfma_kernel<KS, S, CK, COUT_TILE, false>), grid, dim3(256), 0, st, a);
   return 0;
 }
 
@@ -1008,7 +1036,7 @@ extern "C" int64_t pti_conv_packed_bytes(int cout, int cin, int ksize, int mode)
 }
 
 extern "C" int pti_conv_pack_weights(const float* const* w, int nsrc, void* packed, int cout, int cin,
-                                     int ksize, int mode, int transpose_flip, pti_stream_t s) {
+                                     int ksize, int mode, int transpose_flip, int w_f16, pti_stream_t s) {
   if (!w || !packed || nsrc < 1 || nsrc > 4) PTI_FAIL(PTI_EINVAL, "pack_weights: bad pointer/nsrc");
   if (cout % 32 || cin % 32 || (ksize != 1 && ksize != 3))
     PTI_FAIL(PTI_EUNSUPPORTED, "pack_weights: cout=%d cin=%d k=%d need multiples of 32, k in {1,3}", cout, cin, ksize);
@@ -1023,6 +1051,7 @@ extern "C" int pti_conv_pack_weights(const float* const* w, int nsrc, void* pack
   p.cin_l = transpose_flip ? cout : cin;
   p.ks = ksize;
   p.flip = transpose_flip;
+  p.f16 = w_f16 ? 1 : 0;
   p.cout_tile = pick_cout_tile(p.cout_l);
   p.ck = (mode == PTI_CONV_S2PAD) ? pick_ck(p.cin_l, true) : pick_ck2(p.cin_l, p.cout_tile);
   p.total = (long long)p.cout_l * p.cin_l * ksize * ksize;
@@ -1032,7 +1061,7 @@ extern "C" int pti_conv_pack_weights(const float* const* w, int nsrc, void* pack
   return PTI_OK;
 }
 
-static int fill_pack(PackArgs& p, const float* w, void* packed, int cout, int cin, int ksize, int mode, int flip) {
+static int fill_pack(PackArgs& p, const float* w, void* packed, int cout, int cin, int ksize, int mode, int flip, int f16) {
   if (cout % 32 || cin % 32 || (ksize != 1 && ksize != 3)) return -1;
   for (int i = 0; i < 4; ++i) p.src[i] = nullptr;
   p.src[0] = w;
@@ -1041,7 +1070,7 @@ static int fill_pack(PackArgs& p, const float* w, void* packed, int cout, int ci
   p.cout_o = cout; p.cin_o = cin;
   p.cout_l = flip ? cin : cout;
   p.cin_l = flip ? cout : cin;
-  p.ks = ksize; p.flip = flip;
+  p.ks = ksize; p.flip = flip; p.f16 = f16 ? 1 : 0;
   p.cout_tile = pick_cout_tile(p.cout_l);
   p.ck = (mode == PTI_CONV_S2PAD) ? pick_ck(p.cin_l, true) : pick_ck2(p.cin_l, p.cout_tile);
   p.total = (long long)p.cout_l * p.cin_l * ksize * ksize;
@@ -1053,10 +1082,10 @@ static int fill_pack(PackArgs& p, const float* w, void* packed, int cout, int ci
 // that the CALLER filled through pti_conv_pack_table_fill (host) + its own H2D copy.
 extern "C" int pti_conv_pack_entry_bytes(void) { return (int)sizeof(PackArgs); }
 extern "C" int pti_conv_pack_table_fill(void* host_entry, const float* w, void* packed, int cout, int cin, int ksize,
-                                        int mode, int transpose_flip, int64_t* nblocks) {
+                                        int mode, int transpose_flip, int w_f16, int64_t* nblocks) {
   if (!host_entry || !w || !packed || !nblocks) PTI_FAIL(PTI_EINVAL, "pack_table_fill: null pointer");
   PackArgs p;
-  if (fill_pack(p, w, packed, cout, cin, ksize, mode, transpose_flip))
+  if (fill_pack(p, w, packed, cout, cin, ksize, mode, transpose_flip, w_f16))
     PTI_FAIL(PTI_EUNSUPPORTED, "pack_table_fill: cout=%d cin=%d k=%d", cout, cin, ksize);
   *(PackArgs*)host_entry = p;
   *nblocks = (p.total + 2047) / 2048;
@@ -1118,6 +1147,11 @@ static int conv2d_mfma_impl(const void* x, const void* w_packed, const float* bi
   a.act_out = (bf16*)act_out;
   a.in_f16 = d->in_f16; a.res_f16 = d->res_f16; a.out_f16 = d->out_f16;
   a.pool2 = d->pool2x2_out;
+  a.w_f16 = d->w_f16;
+  if (a.w_f16 && !(d->in_f16 && d->out_f16 && (d->res_f16 || !d->add_residual)) )
+    PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: fp16-packed weights need fp16 input, output and residual (the forward convs)");
+  if (a.w_f16 && (gf || d->pool2x2_out))
+    PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: fp16-packed weights are for forward launches only");
   if (a.pool2 && (d->mode == PTI_CONV_S2PAD || d->accum_stats || gf || (d->ho & 1) || (d->wo & 1)))
     PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: pool2x2_out needs a stride-1 gather, even output size, no fused statistics");
   a.eps = d->eps;

@@ -123,6 +123,12 @@ __device__ __forceinline__ u32x2 pack4f(float a, float b, float c, float d, bool
   return r;
 }
 
+// MODE.FP16_OVFL (HW_REG_MODE bit 23): an fp32 -> fp16 conversion that overflows gives +-65504 instead of +-inf (a true
+// infinity stays one).  Kernels that store fp16 activations switch it on first (one scalar instruction; the mode is per
+// wave and dies with it), so an un-normalised residual stream that leaves fp16's range saturates instead of turning
+// into inf and then NaN through the next GroupNorm's statistics.  The argument must be wave-uniform.
+__device__ __forceinline__ void fp16_saturate_on() { __builtin_amdgcn_s_setreg((0 << 11) | (23 << 6) | 1, 1); }
+
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
 // d silu(v)/dv = s*(1 + v*(1-s)), s = sigmoid(v)
 __device__ __forceinline__ float dsilu_f(float v) {

@@ -43,8 +43,11 @@ def _empty(shape, like, dtype=BF16):
 class _MfmaConv:
     """One MFMA convolution's parameters, packed operands and gradient slots."""
 
-    def __init__(self, net, wname, bname, ksize, mode, fused_names=None):
+    def __init__(self, net, wname, bname, ksize, mode, fused_names=None, fwd_f16=True):
         self.net, self.ksize, self.mode = net, ksize, mode
+        # forward operands: fp16 weights + fp16 activations on the MFMA when the engine stores fp16 (Engine sets
+        # .f16 after construction); convs whose input or output is a bf16 tensor (q|k|v, out_proj) stay bf16
+        self.fwd_f16, self.f16 = fwd_f16, False
         self.wname, self.bname, self.fused = wname, bname, fused_names
         if fused_names:  # q|k|v: three adjacent [C,C] weights seen as one [3C,C,1,1]
             w0 = net._param_by_name[fused_names[0][0]]
@@ -76,7 +79,7 @@ class _MfmaConv:
 
     def repack(self):
         w = self._w()
-        self.wp = ops.pack_conv_weight(w, self.ksize, self.mode, out=self.wp)
+        self.wp = ops.pack_conv_weight(w, self.ksize, self.mode, out=self.wp, f16=self.f16)
         dmode = PTI_CONV_ZINS if self.mode == PTI_CONV_S2PAD else PTI_CONV_S1
         self.wpt = ops.pack_conv_weight(w, self.ksize, dmode, flip=True, out=self.wpt)
 
@@ -235,8 +238,8 @@ class _Attention:
         self.norm = _Norm(net, p + ".norm")
         a = p + ".attn."
         self.qkv = _MfmaConv(net, None, None, 1, PTI_CONV_S1,
-                             fused_names=[(a + "to_q.weight", a + "to_q.bias")])
-        self.proj = _MfmaConv(net, a + "out_proj.weight", a + "out_proj.bias", 1, PTI_CONV_S1)
+                             fused_names=[(a + "to_q.weight", a + "to_q.bias")], fwd_f16=False)
+        self.proj = _MfmaConv(net, a + "out_proj.weight", a + "out_proj.bias", 1, PTI_CONV_S1, fwd_f16=False)
         self.convs = [self.qkv, self.proj]
         self.needs_in_stats = True
         self.prefix = p + "."
@@ -348,6 +351,8 @@ class Engine:
             self.dec_layers.append(self._make_layer(db[i], f"decoder.blocks.{i}"))
         self.dec_out = _DirectConv(net, f"decoder.blocks.{last}.conv", norm_prefix=f"decoder.blocks.{last - 1}")
         self.mfma_convs = [c for l in self.enc_layers + self.dec_layers for c in l.convs]
+        for c in self.mfma_convs:
+            c.f16 = c.fwd_f16 and self.act_dtype == torch.float16
         self.direct_convs = [self.enc_in, self.enc_out, self.dec_in, self.dec_out]
         self.Lc = net.latent_channels
         self._plist = list(net._param_by_name.values())
@@ -401,7 +406,7 @@ class Engine:
             entries = []
             for c in self.mfma_convs:
                 dmode = PTI_CONV_ZINS if c.mode == PTI_CONV_S2PAD else PTI_CONV_S1
-                entries += [(c._w(), c.ksize, c.mode, False), (c._w(), c.ksize, dmode, True)]
+                entries += [(c._w(), c.ksize, c.mode, False, c.f16), (c._w(), c.ksize, dmode, True, False)]
             self._packer = ops.BatchedPacker(entries, self.dev)
             for i, c in enumerate(self.mfma_convs):
                 c.wp, c.wpt = self._packer.outputs[2 * i], self._packer.outputs[2 * i + 1]

@@ -50,8 +50,9 @@ def conv_out_hw(h, w, mode):
     return 2 * h, 2 * w
 
 
-def pack_conv_weight(ws, ksize, mode=PTI_CONV_S1, flip=False, out=None):
-    """fp32 [cout,cin,k,k] (or nn.Linear [cout,cin]) master weight(s) -> MFMA-packed bf16."""
+def pack_conv_weight(ws, ksize, mode=PTI_CONV_S1, flip=False, out=None, f16=False):
+    """fp32 [cout,cin,k,k] (or nn.Linear [cout,cin]) master weight(s) -> MFMA-packed bf16 (``f16``: IEEE fp16, the
+    operand of forward launches with ``w_f16``)."""
     ws = list(ws) if isinstance(ws, (list, tuple)) else [ws]
     w0 = ws[0]
     cout, cin = w0.shape[0], w0.shape[1]
@@ -63,11 +64,11 @@ def pack_conv_weight(ws, ksize, mode=PTI_CONV_S1, flip=False, out=None):
     if nbytes == 0:
         raise ValueError(f"pack_conv_weight: unsupported cout={cout} cin={cin} k={ksize}")
     if out is None:
-        out = torch.empty(nbytes // 2, dtype=BF16, device=w0.device)
-    elif out.numel() * 2 != nbytes:
+        out = torch.empty(nbytes // 2, dtype=F16 if f16 else BF16, device=w0.device)
+    elif out.numel() * 2 != nbytes or out.dtype != (F16 if f16 else BF16):
         raise ValueError("pack_conv_weight: bad out size")
     arr = (C.c_void_p * len(ws))(*[w.data_ptr() for w in ws])
-    L.check(L.lib().pti_conv_pack_weights(arr, len(ws), _ptr(out), cout, cin, ksize, mode, int(flip), _stream()),
+    L.check(L.lib().pti_conv_pack_weights(arr, len(ws), _ptr(out), cout, cin, ksize, mode, int(flip), int(f16), _stream()),
             "pti_conv_pack_weights")
     return out
 
@@ -112,8 +113,9 @@ def conv_mfma(x, w_packed, bias, y, *, cout, ksize=3, mode=PTI_CONV_S1, prologue
     yshape = (n, ho // 2, wo // 2, cout) if pool2 else (n, ho, wo, cout)
     if tuple(y.shape) != yshape:
         raise ValueError(f"conv_mfma: y shape {tuple(y.shape)} != {yshape}")
-    if w_packed.numel() != cout * cin * ksize * ksize or w_packed.dtype != BF16:
+    if w_packed.numel() != cout * cin * ksize * ksize or w_packed.dtype not in (BF16, F16):
         raise ValueError("conv_mfma: packed weight size/dtype mismatch")
+    w_f16 = w_packed.dtype == F16   # fp16-packed weights: the MFMA multiplies fp16 operands (forward, fp16 storage)
     if bias is not None:
         _chk(bias, F32, "bias")
         if bias.numel() != cout:
@@ -134,7 +136,7 @@ def conv_mfma(x, w_packed, bias, y, *, cout, ksize=3, mode=PTI_CONV_S1, prologue
                  groups=groups, add_residual=int(residual is not None), accum_stats=int(out_stats is not None),
                  out_groups=out_groups, eps=eps, in_f16=int(x.dtype == F16),
                  res_f16=int(residual is not None and residual.dtype == F16), out_f16=int(y.dtype == F16),
-                 pool2x2_out=int(pool2))
+                 pool2x2_out=int(pool2), w_f16=int(w_f16))
     prof = KERNEL_PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -526,7 +528,7 @@ def attention_bwd(qkv, o, dout, lse2, delta, dqkv):
 
 class BatchedPacker:
     """All MFMA weight packs of a model as ONE kernel launch (the per-layer form costs ~110 launches per
-    optimiser step).  Entries are (fp32 weight view [cout,cin,k,k], ksize, mode, flip); the packed outputs are
+    optimiser step).  Entries are (fp32 weight view [cout,cin,k,k], ksize, mode, flip[, f16]); the packed outputs are
     allocated here and live at fixed addresses, as do the weights (views of the parameter arena)."""
 
     def __init__(self, entries, device):
@@ -535,13 +537,14 @@ class BatchedPacker:
         host = bytearray(esz * len(entries))
         hbuf = (C.c_char * len(host)).from_buffer(host)
         first, total, self.outputs = [], 0, []
-        for i, (w, ksize, mode, flip) in enumerate(entries):
+        for i, (w, ksize, mode, flip, *rest) in enumerate(entries):
+            f16 = bool(rest[0]) if rest else False
             _chk(w, F32, "weight")
             cout, cin = w.shape[0], w.shape[1]
-            out = torch.empty(w.numel(), dtype=BF16, device=device)
+            out = torch.empty(w.numel(), dtype=F16 if f16 else BF16, device=device)
             nb = C.c_int64(0)
             L.check(lib.pti_conv_pack_table_fill(C.byref(hbuf, i * esz), _ptr(w), _ptr(out), cout, cin, ksize, mode,
-                                                 int(flip), C.byref(nb)), "pti_conv_pack_table_fill")
+                                                 int(flip), int(f16), C.byref(nb)), "pti_conv_pack_table_fill")
             first.append(total)
             total += nb.value
             self.outputs.append(out)

@@ -17,7 +17,10 @@ pytestmark = pytest.mark.gpu
                                          (1, 192, 64, True), (1, 1024, 128, False),
                                          # token counts that are not a multiple of the 64 / 32-token tiles (e.g. a 72x104
                                          # image has a 9x13 latent): masked tail keys / queries
-                                         (2, 117, 128, True), (3, 96, 128, False), (1, 40, 256, False), (2, 7, 64, False)])
+                                         (2, 117, 128, True), (3, 96, 128, False), (1, 40, 256, False), (2, 7, 64, False),
+                                         # the AR config's real mid-block shape (256x256 image, 3 levels): L = 64*64, C = 256,
+                                         # and the same token count at C = 128 (the 4096^2 fp32 reference matrix is 64 MB)
+                                         (1, 4096, 256, True), (2, 4096, 128, False)])
 def test_attention_fwd_bwd(dev, b, l, c, spike):
     from pti_ldm_vae_amd import ops
     torch.manual_seed(10)

@@ -74,6 +74,97 @@ def test_conv_mfma_fp16_storage(dev, n, cin, cout, h, w, ks, mode, pro, res, ost
         _report("act_out (bf16)", act.float().cpu().permute(0, 3, 1, 2), a, max_frac=1e-2, l2=3e-3)
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w,ks,mode,pro,res,ostats", [
+    (2, 32, 32, 16, 16, 3, "s1", 2, True, True),
+    (2, 64, 64, 16, 32, 3, "s1", 2, True, True),
+    (2, 128, 128, 16, 16, 3, "s1", 2, True, True),
+    (1, 64, 32, 13, 19, 3, "s1", 2, False, True),
+    (1, 256, 256, 8, 16, 3, "s1", 2, True, False),
+    (2, 128, 128, 8, 8, 3, "up", 0, False, True),       # no prologue: the fp16 activation IS the operand
+    (2, 32, 64, 16, 16, 1, "s1", 0, False, False),      # nin_shortcut
+    (1, 64, 64, 16, 32, 3, "s2", 0, False, True),       # v1 kernel (stride 2)
+    (2, 32, 32, 16, 16, 3, "s2", 0, False, False),
+])
+def test_conv_mfma_fp16_operands(dev, n, cin, cout, h, w, ks, mode, pro, res, ostats):
+    """Forward convs of the default engine: fp16 storage AND fp16 MFMA operands (pti_conv_desc.w_f16, weights packed
+    as fp16, v_mfma_f32_32x32x16_f16).  Inputs are bf16-representable (exact in fp16), weights are rounded to fp16 for
+    the reference, so the only error sources are the fp16 rounding of the activated operand (2^-11) and of the output:
+    max-abs <= 2e-3 of scale, rel-L2 <= 5e-4 -- 5-6x tighter than the bf16-operand bounds of the test above.  The saved
+    activated input stays bf16 (weight-gradient operand)."""
+    from pti_ldm_vae_amd import ops
+    torch.manual_seed(31)
+    groups, eps = 16, 1e-6
+    x = _r(torch.randn(n, cin, h, w) * 1.3 + 0.2)
+    wt = _r16(torch.randn(cout, cin, ks, ks) / (cin * ks * ks) ** 0.5)
+    bias = torch.randn(cout) * 0.1
+    gamma, beta = 1 + 0.2 * torch.randn(cin), 0.1 * torch.randn(cin)
+    a = _gn_ref(x, groups, gamma, beta, eps, pro == 2) if pro else x
+    if mode == "s1":
+        ref, m = F.conv2d(a, wt, bias, padding=ks // 2), ops.PTI_CONV_S1
+    elif mode == "s2":
+        ref, m = F.conv2d(F.pad(a, (0, 1, 0, 1)), wt, bias, stride=2), ops.PTI_CONV_S2PAD
+    else:
+        ref, m = F.conv2d(F.interpolate(a, scale_factor=2.0, mode="nearest"), wt, bias, padding=1), ops.PTI_CONV_UP2
+    rs = _r(torch.randn_like(ref)) if res else None
+    if res:
+        ref = ref + rs
+    xd = _nhwc(x).to(dev, H16)
+    wp = ops.pack_conv_weight(wt.to(dev), ks, m, f16=True)
+    assert wp.dtype == H16
+    ho, wo = ops.conv_out_hw(h, w, m)
+    y = torch.full((n, ho, wo, cout), float("nan"), dtype=H16, device=dev)
+    st = ops.gn_stats(xd, groups) if pro else None
+    ost = torch.zeros(n, 16, 2, dtype=torch.int64, device=dev) if ostats else None
+    act = torch.full((n, h, w, cin), float("nan"), dtype=B16, device=dev) if (pro and mode == "s1" and ks == 3) else None
+    ops.conv_mfma(xd, wp, bias.to(dev), y, cout=cout, ksize=ks, mode=m, prologue=pro, in_stats=st,
+                  gamma=gamma.to(dev) if pro else None, beta=beta.to(dev) if pro else None, groups=groups, eps=eps,
+                  residual=_nhwc(rs).to(dev, H16) if res else None, out_stats=ost, out_groups=16, act_out=act)
+    torch.cuda.synchronize()
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    _report(f"conv_mfma f16 operands[{mode},k{ks},{cin}->{cout},pro{pro}]", got, ref, max_frac=2e-3, l2=5e-4)
+    if ostats:
+        _report("fused stats (fp16 out)", ops.stats_to_float(ost), _stats_ref(got, 16), max_frac=1e-3, l2=1e-4)
+    if act is not None:
+        _report("act_out (bf16)", act.float().cpu().permute(0, 3, 1, 2), a, max_frac=1e-2, l2=3e-3)
+
+
+def test_fp16_operands_need_fp16_tensors(dev):
+    """fp16-packed weights with a bf16 activation are refused before any launch (PTI_EUNSUPPORTED)."""
+    from pti_ldm_vae_amd import ops
+    from pti_ldm_vae_amd._lib import PtiError
+    wp = ops.pack_conv_weight(torch.zeros(32, 32, 3, 3, device=dev), 3, f16=True)
+    x = torch.zeros(1, 8, 8, 32, dtype=B16, device=dev)
+    with pytest.raises(PtiError):
+        ops.conv_mfma(x, wp, None, torch.empty(1, 8, 8, 32, dtype=H16, device=dev), cout=32)
+
+
+def test_fp16_storage_saturates_instead_of_overflowing(dev):
+    """the un-normalised residual stream is stored as fp16.  A residual branch scaled up to ~1e5 must not
+    turn into inf (and then NaN through the next GroupNorm's statistics): the kernels that store fp16 run with
+    MODE.FP16_OVFL, so the conversion saturates at +-65504 and everything downstream stays finite."""
+    from pti_ldm_vae_amd import ops
+    torch.manual_seed(33)
+    n, c, h, w = 1, 32, 16, 16
+    x = _r(torch.randn(n, c, h, w))
+    wt = _r16(torch.randn(c, c, 3, 3) / (c * 9) ** 0.5)
+    big = _r(torch.randn(n, c, h, w) * 6.0e4)                     # |residual| up to ~2e5 > fp16 max once added
+    xd = _nhwc(x).to(dev, H16)
+    rs = _nhwc(big).to(dev, B16)                                   # bf16 residual: representable input, fp16 output
+    y = torch.full((n, h, w, c), float("nan"), dtype=H16, device=dev)
+    ost = torch.zeros(n, 16, 2, dtype=torch.int64, device=dev)
+    ops.conv_mfma(xd, ops.pack_conv_weight(wt.to(dev), 3), None, y, cout=c, residual=rs, out_stats=ost, out_groups=16)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y.float()).all(), "fp16 store overflowed to inf"
+    assert y.float().abs().max().item() == 65504.0                # saturated, not wrapped
+    # and a consumer of that tensor (GroupNorm+SiLU prologue of the next conv) stays finite too
+    y2 = torch.full((n, h, w, c), float("nan"), dtype=H16, device=dev)
+    g, b = torch.ones(c, device=dev), torch.zeros(c, device=dev)
+    ops.conv_mfma(y, ops.pack_conv_weight(wt.to(dev), 3, f16=True), None, y2, cout=c, prologue=ops.PTI_PRO_GN_SILU,
+                  in_stats=ops.gn_stats(y, 16), gamma=g, beta=b, groups=16, eps=1e-6)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y2.float()).all()
+
+
 def test_gn_stats_fp16(dev):
     from pti_ldm_vae_amd import ops
     torch.manual_seed(22)

@@ -1,15 +1,15 @@
-"""Model-level GPU parity: the HIP VAEModel (bf16 MFMA operands, fp32 accumulate, fp16-stored forward
-activations) against the CPU fp32 oracle on identical weights, inputs and eps.
+"""Model-level GPU parity: the HIP VAEModel (fp16 MFMA operands + fp16-stored activations in the forward pass, bf16
+operands in the backward pass, fp32 accumulate) against the CPU fp32 oracle on identical weights, inputs and eps.
 
-Stated tolerances (BASELINE.json / SURVEY.md §8d):
-  * reconstruction of the forward pass with the shared eps: per-pixel MSE <= 1e-4 (target of north_star);
-    measured 4.7e-5 (A@64), 5.1e-5 (AR@64), 5.0e-5 (A@256) -- the remainder is bf16 rounding of the MFMA
-    operands (with bf16-stored activations it was 9.2e-5 .. 1.04e-4).  The eps-free reconstruction decode(mu)
-    is printed too (1.2e-4 .. 2.1e-4: the decoder amplifies the encoder's 1e-2 relative error ~3x when no
-    sampling noise dominates z); it is reported, not gated;
-  * z_mu and log(sigma): relative L2 <= 2e-2;
-  * one training step: loss scalars within 1e-2 relative, whole-gradient cosine >= 0.995,
-    per-tensor cosine >= 0.98 for every tensor with >= 1024 elements.
+Stated tolerances (BASELINE.json / SURVEY.md 8d):
+  * reconstruction, per-pixel MSE <= 1e-4 (north_star), for BOTH the forward pass with the shared eps and the eps-free
+    reconstruct_deterministic(x) = decode(mu) that inference_vae.py / evaluate_vae.py call.  Measured (round 2, fp16
+    forward operands): 1.6e-6 .. 3.7e-6 sampled, 5.2e-6 .. 9.5e-6 deterministic over A@64, AR@64, A@256, A3@64, AR@256
+    (round 1, bf16 operands: 5e-5 and 1.2e-4 .. 2.1e-4 -- the deterministic path missed the bound);
+  * z_mu and log(sigma): relative L2 <= 2e-2 (measured 1.5e-3 .. 2.0e-3);
+  * one training step: loss scalars within 1e-3 relative, whole-gradient cosine >= 0.999 (SURVEY 8d's numbers; measured
+    0.9997+), per-tensor cosine >= 0.995 for every tensor with >= 1024 elements; the native trainer's parameters after
+    one Adam step against the oracle's: test_native_trainer_step_vs_oracle_full_size_image.
 """
 import os
 
@@ -49,7 +49,13 @@ def _rel(a, b):
     return ((a - b).norm() / b.norm()).item()
 
 
-@pytest.mark.parametrize("tag,batch,size", [("A", 2, 64), ("AR", 1, 64), ("A", 1, 256), ("A3", 2, 64)])
+def _cos(a, b):
+    """cosine in float64 (an fp32 dot product over 4.5 M elements is itself only good to ~1e-3)"""
+    a, b = a.double().flatten(), b.double().flatten()
+    return (a @ b / (a.norm() * b.norm())).item()
+
+
+@pytest.mark.parametrize("tag,batch,size", [("A", 2, 64), ("AR", 1, 64), ("A", 1, 256), ("A3", 2, 64), ("AR", 1, 256)])
 def test_forward_parity(dev, tag, batch, size):
     from oracle.autoencoderkl import CONFIG_A, CONFIG_AR
     cfg = CONFIG_A if tag == "A" else CONFIG_AR
@@ -72,8 +78,10 @@ def test_forward_parity(dev, tag, batch, size):
     assert rec.shape == x.shape and mu.shape == eps.shape
     assert _rel(mu, mu_o) <= 2e-2
     assert _rel(sig.log(), sig_o.log()) <= 2e-2
-    # float-atomic GroupNorm statistics move the value by a few % run to run; 2x margin to the target
     assert mse <= 1e-4
+    # the eps-free reconstruction decode(mu) -- what inference_vae.py:78 / evaluate_vae.py:85 call through
+    # VAEModel.reconstruct_deterministic (autoencoder.py:153-163) -- is held to the same north_star bound
+    assert mse_det <= 1e-4
 
 
 def test_golden_vectors_A64(dev):
@@ -112,8 +120,8 @@ def test_training_step_parity(dev, tag):
     torch.cuda.synchronize()
     print(f"[{tag}] loss {loss.item():.6f} vs {loss_o.item():.6f} | recon {rec_l.item():.6f} vs {rec_l_o.item():.6f} | "
           f"kl {kl.item():.4f} vs {kl_o.item():.4f}")
-    assert loss.item() == pytest.approx(loss_o.item(), rel=1e-2)
-    assert kl.item() == pytest.approx(kl_o.item(), rel=1e-2)
+    assert loss.item() == pytest.approx(loss_o.item(), rel=1e-3)
+    assert kl.item() == pytest.approx(kl_o.item(), rel=1e-3)
     go = {n: p.grad for n, p in oracle.named_parameters()}
     worst, flat_g, flat_o = (1.0, ""), [], []
     for n, p in model.autoencoder.named_parameters():
@@ -123,15 +131,15 @@ def test_training_step_parity(dev, tag):
         flat_g.append(g.flatten())
         flat_o.append(go[n].flatten())
         if g.numel() >= 1024:
-            cos = torch.nn.functional.cosine_similarity(g.flatten(), go[n].flatten(), dim=0).item()
+            cos = _cos(g, go[n])
             if cos < worst[0]:
                 worst = (cos, n)
     fg, fo = torch.cat(flat_g), torch.cat(flat_o)
-    cos_all = torch.nn.functional.cosine_similarity(fg, fo, dim=0).item()
+    cos_all = _cos(fg, fo)
     print(f"[{tag}] grad cosine (all) {cos_all:.5f}  norm ratio {(fg.norm() / fo.norm()).item():.4f}  worst tensor {worst}")
-    assert cos_all >= 0.995
-    assert worst[0] >= 0.98, worst
-    assert abs((fg.norm() / fo.norm()).item() - 1.0) <= 5e-2
+    assert cos_all >= 0.999
+    assert worst[0] >= 0.995, worst
+    assert abs((fg.norm() / fo.norm()).item() - 1.0) <= 1e-2
     # gradients alias the flat gradient arena (what the data-parallel loop all-reduces)
     ae = model.autoencoder
     n0, p0 = next(iter(ae.named_parameters()))
@@ -152,7 +160,6 @@ def test_api_surface(dev):
         z = model.encode_stage_2_inputs(xd)
         assert z.shape == mu.shape
         zm = model.encode_deterministic(xd)
-        # GroupNorm statistics are summed with float atomics -> run-to-run differences of a few bf16 ulps
         assert torch.allclose(zm, mu, atol=2e-2, rtol=2e-2)
         assert model.decode_stage_2_outputs(zm).shape == xd.shape
         assert (model.reconstruct_deterministic(xd) - model.decode_stage_2_outputs(zm)).pow(2).mean().item() < 5e-4
@@ -205,19 +212,19 @@ def test_ragged_batch_and_non_square_image(dev):
     loss = torch.nn.functional.l1_loss(rec, xd) + 1e-3 * compute_kl_loss(mu, sig)
     loss.backward()
     torch.cuda.synchronize()
-    assert loss.item() == pytest.approx(loss_o.item(), rel=1e-2)
+    assert loss.item() == pytest.approx(loss_o.item(), rel=1e-3)
     go = {n: p.grad for n, p in oracle.named_parameters()}
     fg = torch.cat([p.grad.detach().cpu().flatten() for _, p in model.autoencoder.named_parameters()])
     fo = torch.cat([go[n].flatten() for n, _ in model.autoencoder.named_parameters()])
-    cos = torch.nn.functional.cosine_similarity(fg, fo, dim=0).item()
+    cos = _cos(fg, fo)
     print(f"[A@72x104 b3] grad cosine {cos:.5f} norm ratio {(fg.norm() / fo.norm()).item():.4f}")
-    assert torch.isfinite(fg).all() and cos >= 0.995
+    assert torch.isfinite(fg).all() and cos >= 0.999
 
 
 def test_full_size_batch_independence_and_finite(dev):
     """BASELINE.json's full size (batch 32, 256x256): the oracle would take minutes, so the check is a size-independent
     property of the path -- GroupNorm is per sample and attention per image, hence every sample's outputs must not
-    depend on what else is in the batch (up to the float-atomic summation order of its own statistics)."""
+    depend on what else is in the batch."""
     from oracle.autoencoderkl import CONFIG_A, synthetic_images
     from pti_ldm_vae_amd.models import VAEModel
     torch.manual_seed(0)
@@ -237,3 +244,57 @@ def test_full_size_batch_independence_and_finite(dev):
     # and an empty batch is refused before any launch
     with pytest.raises((ValueError, RuntimeError)):
         model.autoencoder.encode(torch.zeros(0, 1, 256, 256, device=dev))
+
+
+def test_native_trainer_step_vs_oracle_full_size_image(dev):
+    """ONE optimiser step of the native trainer (VAETrainer.step: HIP forward, fused L1+KL, HIP backward, flat Adam) at
+    config A's real resolution (256x256, batch 2, injected eps) against the oracle's forward + autograd backward +
+    torch.optim.Adam step on the same weights -- a direct comparison of the parameters AFTER the step, not a chain
+    through the drop-in autograd path.
+
+    SURVEY.md 8(d) asks for: loss scalars within 1e-3 relative, update-direction cosine >= 0.999.
+      * loss / recon / kl: gated at 1e-3 relative (measured 3.6e-5).
+      * direction of the gradient arena (what a first-order update follows; float64 cosine): gated at 0.999, measured
+        0.999995 with fp16 forward operands (round 1, bf16 forward operands: 0.997).
+      * the parameters AFTER torch.optim.Adam's first step: Adam's first update is lr * g / (|g| + 1e-8) ~ lr * sign(g),
+        so ITS cosine counts sign agreement element by element with equal weight for a parameter whose gradient is
+        1e-12 (below every 16-bit noise floor; the sign is free) and one whose gradient is 1e-3.  Measured 0.9931 over
+        all 4.56 M parameters and 1.00000 over those with |g| > 1 % of the largest gradient (10 % of them).  The 0.999 of
+        SURVEY 8(d) is therefore gated on the gradient direction and on the update of the parameters above the noise
+        floor (|g| > 1e-3 max|g|); the all-parameter update cosine is gated at the measured 0.99."""
+    from oracle.autoencoderkl import CONFIG_A
+    from oracle.losses import train_step_losses
+    from pti_ldm_vae_amd.trainer import VAETrainer
+    torch.set_num_threads(16)
+    oracle, model = _build(CONFIG_A, dev)
+    x, eps = _inputs(CONFIG_A, 2, 256)
+    lr = 2.5e-5                                       # config/vae_dente_no_adv.json
+    p0 = {n: p.detach().clone() for n, p in oracle.named_parameters()}
+    opt = torch.optim.Adam(oracle.parameters(), lr=lr)
+    opt.zero_grad(set_to_none=True)
+    loss_o, rec_o, kl_o, _ = train_step_losses(oracle, x, eps)
+    loss_o.backward()
+    g_o = torch.cat([p.grad.flatten() for _, p in oracle.named_parameters()])
+    opt.step()
+    d_o = torch.cat([(p.detach() - p0[n]).flatten() for n, p in oracle.named_parameters()])
+
+    tr = VAETrainer(model, lr=lr)
+    out = tr.step(x.to(dev), eps.to(dev))
+    torch.cuda.synchronize()
+    ae = model.autoencoder
+    g_h = torch.cat([ae.grad_view(n).detach().cpu().flatten() for n, _ in ae.named_parameters()])
+    d_h = torch.cat([(p.detach().cpu() - p0[n]).flatten() for n, p in ae.named_parameters()])
+    cos_g, cos_d = _cos(g_h, g_o), _cos(d_h, d_o)
+    big = g_o.abs() > 1e-3 * g_o.abs().max()          # parameters whose gradient is above the 16-bit noise floor
+    cos_d_big = _cos(d_h[big], d_o[big])
+    rel = lambda a, b: abs(a - b) / abs(b)
+    print(f"[native step A@256 b2] loss {out['loss'].item():.6f} vs {loss_o.item():.6f} (rel {rel(out['loss'].item(), loss_o.item()):.2e}) "
+          f"recon rel {rel(out['recon'].item(), rec_o.item()):.2e} kl rel {rel(out['kl'].item(), kl_o.item()):.2e} | "
+          f"grad cosine {cos_g:.5f} norm ratio {(g_h.norm() / g_o.norm()).item():.4f} | Adam update cosine {cos_d:.5f} "
+          f"(|g| > 1e-3 max|g|, {int(big.sum())} params: {cos_d_big:.5f})")
+    assert torch.isfinite(d_h).all()
+    assert out["loss"].item() == pytest.approx(loss_o.item(), rel=1e-3)
+    assert out["recon"].item() == pytest.approx(rec_o.item(), rel=1e-3)
+    assert out["kl"].item() == pytest.approx(kl_o.item(), rel=1e-3)
+    assert cos_g >= 0.999 and abs((g_h.norm() / g_o.norm()).item() - 1.0) <= 1e-2
+    assert cos_d >= 0.99 and cos_d_big >= 0.999
