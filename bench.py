@@ -129,9 +129,19 @@ def main():
     tr = cfg["autoencoder_train"]
     torch.manual_seed(42)                       # set_determinism(args.seed), train_vae.py:808
     model = VAEModel.from_config(cfg_def).to(dev)
+    # AR-VAE configs (ar_vae_dente_kl1e3.json): the attribute-regularisation term is part of the step; attributes are
+    # U(0,1) per sample for the mapped names
+    from pti_ldm_vae_amd.trainer import ARSettings
+    from pti_ldm_vae_amd.utils import resolve_ar_settings
+    ar_on, ar_gamma, _, _ = resolve_ar_settings(tr, cfg.get("regularized_attributes"))
+    ar = ARSettings.from_config(cfg["regularized_attributes"], ar_gamma, cfg_def["latent_channels"]) if ar_on else None
     trainer = VAETrainer(model, lr=tr["lr"], world_size=world, recon_loss=tr["recon_loss"], kl_weight=tr["kl_weight"],
-                         rank_eps_offset=rank)
+                         rank_eps_offset=rank, ar=ar)
     images = synthetic_batch(args.batch, cfg_def["in_channels"], args.size, dev, seed=42 + rank)
+    attrs = None
+    if ar is not None:
+        ga = torch.Generator(device=dev).manual_seed(4242 + rank)
+        attrs = {k: torch.rand(args.batch, generator=ga, device=dev) for k in ar.names}
 
     def sync_all():
         if world > 1:
@@ -144,7 +154,7 @@ def main():
 
     log(f"model built, {sum(p.numel() for p in model.parameters())} params; warm-up {args.warmup} steps")
     for i in range(args.warmup):
-        trainer.step(images)
+        trainer.step(images, attributes=attrs)
         if i == 0:
             torch.cuda.synchronize()
             log("first step done")
@@ -152,7 +162,7 @@ def main():
     log(f"timing {args.steps} steps")
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = trainer.step(images)
+        out = trainer.step(images, attributes=attrs)
     sync_all()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -172,7 +182,7 @@ def main():
     side = trainer.eng.wgrad_stream
     trainer.eng.wgrad_stream = None
     for _ in range(2):          # EVERY rank steps (the step contains collectives); only rank 0 records
-        trainer.step(images)
+        trainer.step(images, attributes=attrs)
     torch.cuda.synchronize()
     trainer.eng.wgrad_stream = side
     if rank == 0:
@@ -228,7 +238,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"config/{os.path.basename(args.config)} {args.size}x{args.size}x{cfg_def['in_channels']} "
-                                   f"batch {args.batch}/GPU: fwd + L1 + 1e-3*KL + bwd + all-reduce + Adam "
+                                   f"batch {args.batch}/GPU: fwd + L1 + 1e-3*KL{' + 0.5*AR-VAE(6 attributes)' if ar else ''} + bwd + all-reduce + Adam "
                                    "(perceptual/adversarial terms omitted: unavailable offline / inactive before epoch 6)",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss, 5)},
             "model_tflops_per_gpu": round(per_gpu * gflop_img / 1e3, 1) if gflop_img else None,

@@ -242,6 +242,16 @@ int pti_vae_loss(const float* recon, const float* images, int64_t npix, const fl
                  float* d_mu, float* d_third, float* workspace, int l2, int third_mode,
                  float kl_weight, pti_stream_t s);
 
+/* ---- AR-VAE attribute regularisation (reference src/pti_ldm_vae/models/losses.py:69-166; train_vae.py:403-417) */
+/* mu: fp32 [b,l,hw] (NCHW z_mu); attrs: fp32 [na,b] attribute values of the local batch; channels[q] / deltas[q]:
+ * latent channel and tanh slope of attribute q; pair_mask: NULL = every ordered pair i != j ("all"), else uint8
+ * [na,b,b] with mask[q][i][j] != 0 for the sampled pairs ("subset").  Writes per_attr[q] = mean over the selected pairs
+ * with a_i != a_j of (tanh(delta (z_j - z_i)) - sign(a_j - a_i))^2 with z = mu.mean(hw) (0 when no pair qualifies) and
+ * counts[q] = that number of pairs; d_mu (NULL to skip) += gamma * d(sum_q per_attr[q]) / d mu.  No atomics.        */
+int pti_ar_vae_loss(const float* mu_nchw, int b, int l, int hw, const float* attrs, const int32_t* channels,
+                    const float* deltas, int na, const uint8_t* pair_mask, float gamma, float* per_attr,
+                    int32_t* counts, float* d_mu, pti_stream_t s);
+
 /* ---- optimiser (torch.optim.Adam defaults, train_vae.py:301) on a flat fp32 arena ----------- */
 int pti_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                   float beta2, float eps, int step, float grad_scale, pti_stream_t s);

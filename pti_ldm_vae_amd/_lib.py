@@ -70,6 +70,7 @@ SIGNATURES = {
     "pti_post_quant_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "pti_latent_head_bwd": (_I, [_P] * 19 + [_I, _I, _I, _P]),
     "pti_vae_loss": (_I, [_P, _P, _I64, _P, _P, _I64, _I, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
+    "pti_ar_vae_loss": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _P, _F, _P, _P, _P, _P]),
     "pti_adam_step": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I, _F, _P]),
     "pti_preprocess_batch": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "pti_cast_nchw_f32_to_nhwc_bf16": (_I, [_P, _P, _I, _I, _I, _P]),

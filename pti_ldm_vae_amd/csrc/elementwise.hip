@@ -334,6 +334,111 @@ __global__ __launch_bounds__(256) void cast_nhwc_bf16_to_nchw_f32(const bf16* __
   }
 }
 
+// ---- AR-VAE attribute regularisation (reference src/pti_ldm_vae/models/losses.py:69-166; call site ------------------
+// vae_scripts/train_vae.py:403-417).  z = z_mu.mean(h, w); for every attribute mapped to latent channel ch with slope
+// delta: over the ordered pairs (i, j), i != j, of the local batch (optionally a sampled subset, given as a byte mask)
+// whose attribute values differ, mean of (tanh(delta * (z_j - z_i)) - sign(a_j - a_i))^2.  One workgroup per latent
+// channel (it walks the attributes mapped to that channel in order, so two attributes on one channel never race):
+// wave-per-sample spatial means, thread-per-sample row/column sums over the b x b pair grid (every sum in a fixed
+// order: no atomics, bitwise reproducible), and the gradient gamma * d(sum of the per-attribute losses)/d z_mu is
+// ADDED to d_mu (the same value at each of the hw positions of (sample, ch): d mean / d element = 1 / hw).
+constexpr int AR_MAXB = 1024;
+struct ArArgs {
+  const float* mu;        // [b][l][hw]
+  const float* attrs;     // [na][b]
+  const int* channels;    // [na]
+  const float* deltas;    // [na]
+  const unsigned char* mask;   // [na][b][b] or nullptr (= every ordered pair)
+  float* per_attr;        // [na]
+  int* counts;            // [na]
+  float* d_mu;            // [b][l][hw] or nullptr
+  int b, l, hw, na;
+  float gamma;
+};
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {   // fixed order: wave shuffles, then 4 partials
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void ar_vae_kernel(ArArgs a) {
+  __shared__ float z[AR_MAXB], at[AR_MAXB], dz[AR_MAXB], red[4];
+  const int ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  bool mine = false;
+  for (int q = 0; q < a.na; ++q) mine |= (a.channels[q] == ch);
+  if (!mine) return;   // block-uniform
+  const float inv_hw = 1.0f / (float)a.hw;
+  for (int s = wave; s < a.b; s += 4) {   // spatial mean of (sample s, channel ch)
+    const float* p = a.mu + ((size_t)s * a.l + ch) * a.hw;
+    float acc = 0.f;
+    for (int i = lane; i < a.hw; i += 64) acc += p[i];
+    acc = wave_sum(acc);
+    if (lane == 0) z[s] = acc * inv_hw;
+  }
+  for (int s = tid; s < a.b; s += 256) dz[s] = 0.f;
+  __syncthreads();
+  for (int q = 0; q < a.na; ++q) {
+    if (a.channels[q] != ch) continue;
+    const float delta = a.deltas[q];
+    const unsigned char* m = a.mask ? a.mask + (size_t)q * a.b * a.b : nullptr;
+    for (int s = tid; s < a.b; s += 256) at[s] = a.attrs[(size_t)q * a.b + s];
+    __syncthreads();
+    // pass 1: loss numerator and pair count, row k per thread
+    float num = 0.f, cnt = 0.f;
+    for (int k = tid; k < a.b; k += 256) {
+      const float zk = z[k], ak = at[k];
+      for (int j = 0; j < a.b; ++j) {
+        const float d = at[j] - ak;
+        const float order = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        const bool sel = order != 0.f && j != k && (!m || m[(size_t)k * a.b + j]);
+        if (sel) {
+          const float e = tanhf(delta * (z[j] - zk)) - order;
+          num += e * e;
+          cnt += 1.f;
+        }
+      }
+    }
+    num = block_sum_256(num, red);
+    cnt = block_sum_256(cnt, red);
+    if (tid == 0) {
+      a.per_attr[q] = cnt > 0.f ? num / cnt : 0.f;
+      a.counts[q] = (int)cnt;
+    }
+    // pass 2: d loss_q / d z_k = sum_i G[i][k] - sum_j G[k][j],  G[i][j] = 2 (pred - order) sel delta (1 - pred^2) / cnt
+    if (a.d_mu && cnt > 0.f) {
+      const float sc = 2.0f * delta / cnt;
+      for (int k = tid; k < a.b; k += 256) {
+        const float zk = z[k], ak = at[k];
+        float g = 0.f;
+        for (int i = 0; i < a.b; ++i) {
+          if (i == k) continue;
+          const float d = at[i] - ak;                       // a_i - a_k
+          const float o_ki = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);   // order[k][i] = sign(a_i - a_k); order[i][k] = -o_ki
+          if (o_ki == 0.f) continue;
+          const float p_ki = tanhf(delta * (z[i] - zk));     // pred[k][i]; pred[i][k] = -p_ki
+          const float w = (p_ki - o_ki) * (1.f - p_ki * p_ki);
+          // G[i][k] = sc * (pred[i][k] - order[i][k]) (1 - pred^2) = -sc * w ; G[k][i] = sc * w
+          if (!m || m[(size_t)i * a.b + k]) g -= sc * w;     // + G[i][k]
+          if (!m || m[(size_t)k * a.b + i]) g -= sc * w;     // - G[k][i]
+        }
+        dz[k] += g;
+      }
+    }
+    __syncthreads();
+  }
+  if (a.d_mu) {
+    const float sc = a.gamma * inv_hw;
+    for (int s = 0; s < a.b; ++s) {
+      float* p = a.d_mu + ((size_t)s * a.l + ch) * a.hw;
+      const float g = dz[s] * sc;
+      for (int i = tid; i < a.hw; i += 256) p[i] += g;
+    }
+  }
+}
+
 inline unsigned nblocks(long long total, int cap = 4096) {
   long long b = (total + 255) / 256;
   if (b > cap) b = cap;
@@ -427,11 +532,24 @@ extern "C" int pti_vae_loss(const float* recon, const float* images, int64_t npi
   return PTI_OK;
 }
 
+extern "C" int pti_ar_vae_loss(const float* mu_nchw, int b, int l, int hw, const float* attrs, const int32_t* channels,
+                               const float* deltas, int na, const uint8_t* pair_mask, float gamma, float* per_attr,
+                               int32_t* counts, float* d_mu, pti_stream_t s) {
+  if (!mu_nchw || !attrs || !channels || !deltas || !per_attr || !counts) PTI_FAIL(PTI_EINVAL, "ar_vae_loss: null pointer");
+  if (b <= 0 || l <= 0 || hw <= 0 || na <= 0) PTI_FAIL(PTI_EINVAL, "ar_vae_loss: bad sizes");
+  if (b > AR_MAXB) PTI_FAIL(PTI_EUNSUPPORTED, "ar_vae_loss: local batch %d above %d", b, AR_MAXB);
+  ArArgs a{mu_nchw, attrs, channels, deltas, pair_mask, per_attr, counts, d_mu, b, l, hw, na, gamma};
+  hipLaunchKernelGGL(ar_vae_kernel, dim3(l), dim3(256), 0, (hipStream_t)s, a);
+  PTI_CHECK_LAUNCH("ar_vae_loss");
+  return PTI_OK;
+}
+
 extern "C" int pti_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                              float beta2, float eps, int step, float grad_scale, pti_stream_t s) {
   if (!p || !g || !m || !v || n <= 0 || step < 1) PTI_FAIL(PTI_EINVAL, "adam_step: bad args");
-  const float bc1 = 1.f - powf(beta1, (float)step);
-  const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  // bias corrections in double, as torch.optim.Adam computes them (fp32 powf left ~1e-5 relative error at small steps)
+  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
   hipLaunchKernelGGL(adam_kernel, dim3(nblocks(n, 2048)), dim3(256), 0, (hipStream_t)s, p, g, m, v, (long long)n, lr, beta1,
                      beta2, eps, bc1, bc2s, grad_scale);
   PTI_CHECK_LAUNCH("adam_step");

@@ -10,8 +10,10 @@ chain ``LoadImage -> EnsureChannelFirst -> Resize(patch_size) -> LocalNormalizeB
   stream waits on.  Two batches are in flight (double buffering), so decode + copy + preprocessing of batch k+1
   overlap the optimiser step of batch k.
 
-Not mirrored (stated, not silently dropped): attribute files of the AR-VAE branch, ``cache_rate`` (the whole decoded
-set is small enough to keep in page cache), MONAI meta-tensors.  Axis order: the TIFF is taken row-major as (H, W);
+AR-VAE: with ``ar_vae_enabled`` the per-image attributes (``data/attributes.py``) ride along and a batch is the pair
+``(images, {name: float32 [b] device tensor})`` -- what ``collate_with_attributes`` (dataloaders.py:108-117) yields, already
+on the device.  Not mirrored (stated, not silently dropped): ``cache_rate`` (the whole decoded set is small enough to
+keep in page cache), MONAI meta-tensors.  Axis order: the TIFF is taken row-major as (H, W);
 which reader MONAI's ``LoadImage`` picks for ``.tif`` (and whether it transposes) cannot be checked offline -- with
 the square patches of every reference config this only mirrors the image, it does not change the statistics.
 """
@@ -89,10 +91,14 @@ class DeviceImageLoader:
     safe to use on the current stream; it stays valid until two further batches have been requested."""
 
     def __init__(self, paths: list[str], batch_size: int, patch_size: tuple[int, int], device, *, rank: int = 0,
-                 world_size: int = 1, shuffle: bool = True, seed: int = 42, num_workers: int = 4):
+                 world_size: int = 1, shuffle: bool = True, seed: int = 42, num_workers: int = 4,
+                 attributes: list[dict[str, float]] | None = None):
         from .. import ops
         self._ops = ops
         self.paths, self.batch, self.patch = list(paths), int(batch_size), (int(patch_size[0]), int(patch_size[1]))
+        if attributes is not None and len(attributes) != len(self.paths):
+            raise ValueError("DeviceImageLoader: one attribute dict per image path is required")
+        self.attributes = attributes
         self.dev = torch.device(device)
         self.rank, self.world, self.shuffle, self.seed, self.epoch = rank, world_size, shuffle, seed, 0
         self.pool = ThreadPoolExecutor(max_workers=max(1, num_workers))
@@ -138,6 +144,15 @@ class DeviceImageLoader:
             ev = torch.cuda.Event()
             ev.record(self.copy_stream)
         slot["event"], slot["out"], slot["keep"] = ev, out, (desc, hw, d_off, d_hw)
+        slot["attrs"] = None
+        if self.attributes is not None:
+            names = list(self.attributes[idx[0]].keys())
+            host = torch.tensor([[float(self.attributes[i][k]) for i in idx] for k in names], dtype=torch.float32).pin_memory()
+            with torch.cuda.stream(self.copy_stream):
+                dev_attrs = host.to(self.dev, non_blocking=True)
+                ev.record(self.copy_stream)
+            slot["keep"] += (host,)
+            slot["attrs"] = (names, dev_attrs)
         return slot
 
     def __iter__(self):
@@ -156,25 +171,40 @@ class DeviceImageLoader:
                 pending = self._stage(nxt, batches[k + 1])
             torch.cuda.current_stream(self.dev).wait_event(cur["event"])
             cur["out"].record_stream(torch.cuda.current_stream(self.dev))
-            yield cur["out"]
+            if cur["attrs"] is None:
+                yield cur["out"]
+            else:
+                names, table = cur["attrs"]
+                table.record_stream(torch.cuda.current_stream(self.dev))
+                yield cur["out"], {k: table[i] for i, k in enumerate(names)}
 
 
 def create_vae_dataloaders(data_base_dir: str, batch_size: int, patch_size: tuple[int, int], rank: int = 0,
                            data_source: str = "edente", train_split: float = 0.9, num_workers: int = 4,
                            seed: int | None = 42, subset_size: int | None = None, val_dir: str | None = None,
-                           distributed: bool = False, world_size: int = 1, device="cuda", **_ignored):
-    """Same signature prefix and return shape as the reference's ``create_vae_dataloaders``:
-    ``(train_loader, val_loader, train_paths, val_paths)`` with loaders that yield device batches."""
+                           cache_rate: float = 0.0, distributed: bool = False, world_size: int = 1,
+                           ar_vae_enabled: bool = False, regularized_attributes: dict | None = None, device="cuda",
+                           **_ignored):
+    """Same signature and return shape as the reference's ``create_vae_dataloaders`` (dataloaders.py:370-593):
+    ``(train_loader, val_loader, train_paths, val_paths)`` with loaders that yield device batches -- ``images``, or
+    ``(images, attributes)`` when ``ar_vae_enabled``."""
     if not 0 < train_split < 1:
         raise ValueError(f"train_split must be in (0, 1), got {train_split}")
     paths = list_tif_paths(data_base_dir, data_source)
     val_list = list_tif_paths(val_dir, data_source) if val_dir is not None else None
     train_paths, val_paths = split_paths(paths, train_split, seed, subset_size, val_list)
+    if not 0.0 <= cache_rate <= 1.0:
+        raise ValueError(f"cache_rate must be in [0, 1], got {cache_rate}")
+    train_attrs = val_attrs = None
+    if ar_vae_enabled:
+        from .attributes import attributes_for_paths
+        train_attrs = attributes_for_paths(train_paths, regularized_attributes, data_source)
+        val_attrs = attributes_for_paths(val_paths, regularized_attributes, data_source)
     world = world_size if distributed else 1
     r = rank if distributed else 0
     s = seed if seed is not None else 0
     train = DeviceImageLoader(train_paths, batch_size, patch_size, device, rank=r, world_size=world, shuffle=True, seed=s,
-                              num_workers=num_workers)
+                              num_workers=num_workers, attributes=train_attrs)
     val = DeviceImageLoader(val_paths, batch_size, patch_size, device, rank=r, world_size=world, shuffle=False, seed=s,
-                            num_workers=num_workers)
+                            num_workers=num_workers, attributes=val_attrs)
     return train, val, train_paths, val_paths

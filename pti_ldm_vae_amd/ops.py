@@ -472,6 +472,30 @@ def vae_loss(recon, images, mu, third, out2, d_recon, d_mu, d_third, *, l2=False
                                  third_mode, kl_weight, _stream()), "pti_vae_loss")
 
 
+def ar_vae_loss(mu, attrs, channels, deltas, per_attr, counts, *, gamma=0.0, d_mu=None, pair_mask=None):
+    """AR-VAE term on the device (``pti_ar_vae_loss``): mu [b,l,h,w] fp32, attrs [na,b] fp32, channels int32 [na],
+    deltas fp32 [na] -> per_attr fp32 [na], counts int32 [na]; ``d_mu`` (same shape as mu) += gamma * gradient."""
+    _chk(mu, F32, "mu", 4)
+    _chk(attrs, F32, "attrs", 2)
+    _chk(deltas, F32, "deltas")
+    _chk(per_attr, F32, "per_attr")
+    b, l, h, w = mu.shape
+    na = attrs.shape[0]
+    if attrs.shape[1] != b or channels.numel() != na or deltas.numel() != na or per_attr.numel() != na or counts.numel() != na:
+        raise ValueError("ar_vae_loss: attrs must be [na, b]; channels / deltas / per_attr / counts [na]")
+    if channels.dtype != torch.int32 or counts.dtype != torch.int32 or not (channels.is_cuda and counts.is_cuda):
+        raise TypeError("ar_vae_loss: channels / counts must be int32 device tensors")
+    if d_mu is not None:
+        _chk(d_mu, F32, "d_mu", 4)
+        if d_mu.shape != mu.shape:
+            raise ValueError("ar_vae_loss: d_mu shape")
+    if pair_mask is not None:
+        if pair_mask.dtype != torch.uint8 or tuple(pair_mask.shape) != (na, b, b) or not pair_mask.is_cuda or not pair_mask.is_contiguous():
+            raise ValueError("ar_vae_loss: pair_mask must be a contiguous uint8 device tensor [na, b, b]")
+    L.check(L.lib().pti_ar_vae_loss(_ptr(mu), b, l, h * w, _ptr(attrs), _ptr(channels), _ptr(deltas), na, _ptr(pair_mask),
+                                    float(gamma), _ptr(per_attr), _ptr(counts), _ptr(d_mu), _stream()), "pti_ar_vae_loss")
+
+
 def adam_step(p, g, m, v, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, step=1, grad_scale=1.0):
     for t, nm in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
         _chk(t, F32, nm)

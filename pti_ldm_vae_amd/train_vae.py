@@ -14,10 +14,12 @@ What is different, on purpose:
     unused-parameter search, no ``detect_anomaly``; ``--detect-anomaly`` is not needed without a tape);
   * the perceptual (LPIPS) and adversarial terms are NOT available here (they need packages/weights that are
     not installable offline): ``perceptual_weight`` and ``adv_enabled`` are read and reported, and must be
-    0/false — or pass ``--ignore-unavailable-terms`` to train with recon+KL(+AR is drop-in only) and a warning;
-  * data: the TIFF pipeline (``src/pti_ldm_vae/data``) is out of scope for this round (SURVEY.md §8f N1);
-    ``--synthetic N`` trains on N seeded synthetic images of the configured patch size (z-scored elliptical
-    foreground, zero background), sharded across ranks like ``DistributedSampler``;
+    0/false — or pass ``--ignore-unavailable-terms`` to train with recon + KL (+ AR-VAE) and a warning;
+  * the AR-VAE term (``regularized_attributes``) IS part of the native step (``pti_ar_vae_loss``);
+  * data: without ``--synthetic`` the TIFF directory of the config is read through the device input pipeline
+    (``pti_ldm_vae_amd.data``: host decode -> one H2D copy -> GPU resize + masked z-score; attribute JSONs joined
+    for AR-VAE); ``--synthetic N`` trains on N seeded synthetic images of the configured patch size (z-scored
+    elliptical foreground, zero background; U(0,1) attributes), sharded across ranks like ``DistributedSampler``;
   * logging goes to ``<run_dir>/metrics.jsonl`` with the reference's W&B metric names
     (``train/recon_loss`` ... ``val/loss_total``), one host sync per ``--log-every`` steps.
 """
@@ -33,7 +35,7 @@ from pathlib import Path
 import torch
 
 from .models import VAEModel, compute_total_loss
-from .trainer import VAETrainer
+from .trainer import ARSettings, VAETrainer, prepare_batch
 from .utils import read_config, resolve_ar_settings
 from .utils.distributed import setup_ddp
 
@@ -91,7 +93,8 @@ class SyntheticShards:
     ``DistributedSampler(shuffle=True, seed)`` does (every world-th index of a seed+epoch permutation,
     wrapped to equal length).  Images are generated on the device, batch by batch."""
 
-    def __init__(self, n, channels, size, batch, rank, world, seed, device, train_split=0.9):
+    def __init__(self, n, channels, size, batch, rank, world, seed, device, train_split=0.9, attr_names=None):
+        self.attr_names = attr_names
         self.n_train = max(1, int(n * train_split))
         self.n_val = max(1, n - self.n_train)
         self.c, self.size, self.batch, self.rank, self.world, self.seed, self.dev = channels, size, batch, rank, world, seed, device
@@ -112,18 +115,29 @@ class SyntheticShards:
     def batches(self, epoch, train=True):
         idx = self._indices(self.n_train, epoch, 0) if train else self._indices(self.n_val, 0, self.n_train)
         for i in range(0, len(idx), self.batch):
-            yield torch.stack([self._image(j) for j in idx[i:i + self.batch]])
+            ids = idx[i:i + self.batch]
+            images = torch.stack([self._image(j) for j in ids])
+            if self.attr_names is None:
+                yield images
+            else:   # U(0,1) attribute values per synthetic sample, fixed by (seed, sample, name) -- SURVEY.md 8(d)
+                yield images, {k: torch.tensor([self._attr(j, q) for j in ids], dtype=torch.float32)
+                               for q, k in enumerate(self.attr_names)}
+
+    def _attr(self, idx, q):
+        g = torch.Generator().manual_seed(self.seed * 7_919 + int(idx) * 131 + q)
+        return float(torch.rand((), generator=g))
 
 
 class TiffShards:
     """The same ``batches(epoch, train)`` interface over a directory of .tif images (pti_ldm_vae_amd.data)."""
 
     def __init__(self, base_dir, batch, patch, rank, world, seed, device, *, data_source, train_split, subset_size, val_dir,
-                 num_workers):
+                 num_workers, ar_vae_enabled=False, regularized_attributes=None):
         from .data import create_vae_dataloaders
         self.train, self.val, self.train_paths, self.val_paths = create_vae_dataloaders(
             base_dir, batch, patch, rank=rank, data_source=data_source, train_split=train_split, num_workers=num_workers,
-            seed=seed, subset_size=subset_size, val_dir=val_dir, distributed=world > 1, world_size=world, device=device)
+            seed=seed, subset_size=subset_size, val_dir=val_dir, distributed=world > 1, world_size=world, device=device,
+            ar_vae_enabled=ar_vae_enabled, regularized_attributes=regularized_attributes)
 
     def batches(self, epoch, train=True):
         loader = self.train if train else self.val
@@ -182,8 +196,6 @@ def main(argv=None):
         unavailable.append(f"perceptual_weight={tr['perceptual_weight']} (LPIPS needs lpips+torchvision+weights)")
     if adv_enabled:
         unavailable.append("adv_enabled=true (PatchDiscriminator branch, active after epoch 5)")
-    if ar_enabled:
-        unavailable.append("AR-VAE loss (needs attribute files; available through the drop-in autograd path)")
     if unavailable:
         msg = "terms not available in the native trainer: " + "; ".join(unavailable)
         if not args.ignore_unavailable_terms:
@@ -202,14 +214,16 @@ def main(argv=None):
     if rank == 0:
         print("\n=== Autoencoder model summary ===\n", model, "\n=================================\n")
     pg = None
+    reg_attrs = getattr(args, "regularized_attributes", {}) or {}
+    ar = ARSettings.from_config(reg_attrs, ar_gamma, args.autoencoder_def["latent_channels"]) if ar_enabled else None
     trainer = VAETrainer(model, lr=tr["lr"], world_size=world, process_group=pg, recon_loss=tr.get("recon_loss", "l1"),
-                         kl_weight=tr["kl_weight"], rank_eps_offset=rank)
+                         kl_weight=tr["kl_weight"], rank_eps_offset=rank, ar=ar)
     start_epoch, best_val, total_step, best_epoch_saved = load_checkpoint(args, model, trainer.opt, device)
     model.autoencoder.mark_weights_dirty()
     if args.synthetic:
         n = args.subset_size or args.synthetic
         data = SyntheticShards(n, args.autoencoder_def["in_channels"], tuple(tr["patch_size"]), tr["batch_size"], rank, world,
-                               args.seed, device, args.train_split)
+                               args.seed, device, args.train_split, attr_names=ar.names if ar else None)
         train_files = [f"synthetic:{i}" for i in range(data.n_train)]
         val_files = [f"synthetic:{i}" for i in range(data.n_train, data.n_train + data.n_val)]
     else:
@@ -218,7 +232,8 @@ def main(argv=None):
             raise SystemExit("train_vae: the TIFF pipeline produces single-channel images (in_channels must be 1)")
         data = TiffShards(args.data_base_dir, tr["batch_size"], tuple(tr["patch_size"]), rank, world, args.seed, device,
                           data_source=getattr(args, "data_source", "edente"), train_split=args.train_split,
-                          subset_size=args.subset_size, val_dir=getattr(args, "val_dir", None), num_workers=args.num_workers)
+                          subset_size=args.subset_size, val_dir=getattr(args, "val_dir", None), num_workers=args.num_workers,
+                          ar_vae_enabled=ar_enabled, regularized_attributes=reg_attrs)
         train_files, val_files = data.train_paths, data.val_paths
     if rank == 0:
         with open(Path(args.run_dir) / "splits" / "vae_split.json", "w", encoding="utf-8") as f:
@@ -229,31 +244,42 @@ def main(argv=None):
     for epoch in range(start_epoch, max_epochs):
         t0 = time.time()
         seen = 0
-        for step, images in enumerate(data.batches(epoch, train=True)):
-            out = trainer.step(images)
+        for step, batch in enumerate(data.batches(epoch, train=True)):
+            images, attrs = prepare_batch(batch, device, ar_enabled)
+            out = trainer.step(images, attributes=attrs)
             total_step += 1
             seen += images.shape[0]
             if log is not None and step % args.log_every == 0:
-                log.write(json.dumps({"train/step": total_step, "train/recon_loss": out["recon"].item(),
-                                      "train/kl_loss": out["kl"].item(), "train/loss_total": out["loss"].item(),
-                                      "train/perceptual_loss": 0.0, "train/adv_gen_loss": 0.0,
-                                      "train/adv_disc_loss": 0.0}) + "\n")
+                rec = {"train/step": total_step, "train/recon_loss": out["recon"].item(),
+                       "train/kl_loss": out["kl"].item(), "train/loss_total": out["loss"].item(),
+                       "train/perceptual_loss": 0.0, "train/adv_gen_loss": 0.0, "train/adv_disc_loss": 0.0}
+                if ar is not None:   # W&B names of train_vae.py:471-478
+                    rec["train/ar_loss_total"] = out["ar"].item()
+                    for name, la, cnt, dl in zip(ar.names, out["ar_per_attr"].tolist(), out["ar_pairs"].tolist(), ar.deltas):
+                        rec[f"train/ar_loss_{name}"], rec[f"train/ar_pairs_{name}"], rec[f"train/ar_delta_{name}"] = la, cnt, dl
+                log.write(json.dumps(rec) + "\n")
                 log.flush()
         if epoch % val_interval == 0:
-            rsum = ksum = torch.zeros((), device=device)
+            rsum = ksum = asum = torch.zeros((), device=device)
             nb = 0
-            for images in data.batches(epoch, train=False):
-                v, _ = trainer.eval_losses(images)
+            for batch in data.batches(epoch, train=False):
+                images, attrs = prepare_batch(batch, device, ar_enabled)
+                v, _ = trainer.eval_losses(images, attributes=attrs)
                 rsum, ksum, nb = rsum + v["recon"], ksum + v["kl"], nb + 1
-            val_recon, val_kl = (rsum / max(nb, 1)).item(), (ksum / max(nb, 1)).item()
-            val_total = compute_total_loss(val_recon, val_kl, 0.0, 0.0, 0.0, kl_weight=kl_w, perceptual_weight=0.0,
-                                           adv_weight=0.0, ar_gamma=ar_gamma, ar_vae_enabled=False)
+                if ar is not None:
+                    asum = asum + v["ar"]
+            val_recon, val_kl, val_ar = ((t / max(nb, 1)).item() for t in (rsum, ksum, asum))
+            val_total = compute_total_loss(val_recon, val_kl, 0.0, 0.0, val_ar, kl_weight=kl_w, perceptual_weight=0.0,
+                                           adv_weight=0.0, ar_gamma=ar_gamma, ar_vae_enabled=ar_enabled)
             torch.cuda.synchronize()
             dt = time.time() - t0
             if rank == 0:
                 print(f"Epoch {epoch} val_loss: {val_recon:.4f} | Time: {dt:.1f}s | {seen * world / dt:.1f} img/s")
-                log.write(json.dumps({"epoch": epoch, "val/recon_loss": val_recon, "val/kl_loss": val_kl,
-                                      "val/loss_total": val_total, "val/perceptual_loss": 0.0, "time_per_epoch": dt}) + "\n")
+                rec = {"epoch": epoch, "val/recon_loss": val_recon, "val/kl_loss": val_kl, "val/loss_total": val_total,
+                       "val/perceptual_loss": 0.0, "time_per_epoch": dt}
+                if ar is not None:
+                    rec["val/ar_loss_total"] = val_ar
+                log.write(json.dumps(rec) + "\n")
                 log.flush()
             best_val, best_epoch_saved = save_checkpoints(args, model, trainer.opt, epoch, val_recon, best_val,
                                                           best_epoch_saved, total_step, rank)

@@ -1,11 +1,16 @@
 """Native training step of the VAE hot path: the body of the reference's ``train_epoch`` loop
 (``vae_scripts/train_vae.py:380-445``) run directly on the HIP engine, without the autograd tape:
 
-    zero_grad -> forward (encode, sample, decode) -> recon (L1|L2) + kl_weight*KL  -> backward
-              -> gradient all-reduce (overlapped with backward, buckets of the flat arena) -> Adam
+    zero_grad -> forward (encode, sample, decode) -> recon (L1|L2) + kl_weight*KL (+ gamma * AR-VAE term)
+              -> backward -> gradient all-reduce (overlapped with backward, buckets of the flat arena) -> Adam
+
+``prepare_batch`` is the reference's ``_prepare_batch`` (train_vae.py:183-243): every container form a dataloader
+may hand over (tensor / ``(images, attributes)`` / list of ``(image, attributes)`` pairs / ``[images, dict]``) becomes
+device tensors.  The AR-VAE term (``compute_ar_vae_loss``, losses.py:69-166, called at train_vae.py:408-415 on
+``z_mu.mean(dim=(2, 3))``) runs as one HIP kernel (``pti_ar_vae_loss``) that also adds its gradient to ``d z_mu``.
 
 Perceptual (LPIPS) and adversarial terms are NOT part of this path (unavailable offline / inactive
-before epoch 6 — SURVEY.md §2); ``perceptual_weight`` must be 0 here and the drop-in autograd path
+before epoch 6 -- SURVEY.md 2); ``perceptual_weight`` must be 0 here and the drop-in autograd path
 (``VAEModel.forward`` + any torch loss) remains available for everything else.  No ``.item()`` on
 the step path: loss scalars come back as device tensors.
 """
@@ -13,6 +18,7 @@ from __future__ import annotations
 
 import collections
 import os
+import random
 
 import torch
 
@@ -21,10 +27,85 @@ from .data_parallel import FlatGradAllReducer, broadcast_parameters
 from .optim import FlatAdam
 
 
+def prepare_batch(batch, device, ar_vae_enabled: bool):
+    """Reference ``_prepare_batch`` (train_vae.py:183-243): -> ``(images on device, attributes dict on device | None)``.
+
+    Accepted: a tensor; a tuple ``(images, attributes)``; a list of ``(image, attributes)`` pairs (a collate that did
+    not stack); a two-element list ``[images, attributes dict]``.  Raises ``ValueError`` for an empty list or for AR-VAE
+    without attributes, ``TypeError`` for anything else -- the reference's exception types and messages."""
+    attrs = None
+    if isinstance(batch, list):
+        if not batch:
+            raise ValueError("Empty batch received from dataloader.")
+        if all(isinstance(it, tuple) and len(it) == 2 for it in batch):
+            images = torch.stack([torch.as_tensor(img) for img, _ in batch], dim=0)
+            buf: dict[str, list] = {}
+            for _, a in batch:
+                if a is not None:
+                    for k, v in a.items():
+                        buf.setdefault(k, []).append(torch.as_tensor(v))
+            if buf:
+                attrs = {k: torch.stack(v, dim=0).to(torch.float32) for k, v in buf.items()}
+        elif len(batch) == 2 and isinstance(batch[0], torch.Tensor) and isinstance(batch[1], dict):
+            images, attrs = batch[0], {k: torch.as_tensor(v) for k, v in batch[1].items()}
+        else:
+            raise TypeError(f"Unsupported list batch elements: {[type(it) for it in batch]}")
+    elif isinstance(batch, tuple):
+        images, attrs = batch
+    else:
+        images = batch
+    if not isinstance(images, torch.Tensor):
+        raise TypeError(f"Unsupported batch type: {type(images)}")
+    images = images.to(device, non_blocking=True)
+    if attrs is not None:
+        attrs = {k: v.to(device, non_blocking=True) for k, v in attrs.items()}
+    elif ar_vae_enabled:
+        raise ValueError("AR-VAE is enabled but attributes are missing from the batch.")
+    return images, attrs
+
+
+class ARSettings:
+    """The AR-VAE block of a run (``regularized_attributes`` of the config, train_vae.py:376-378,776-792) resolved once:
+    attribute names in mapping order, their latent channels and tanh slopes (per-attribute ``delta`` or the
+    ``delta_global`` fall-back, losses.py:118-128), pair mode and gamma.  Validation errors are the reference's."""
+
+    def __init__(self, attribute_latent_mapping: dict, *, gamma: float, pairwise: str = "all", subset_pairs=None,
+                 delta_global: dict | None = None, latent_channels: int | None = None):
+        if pairwise not in {"all", "subset"}:
+            raise ValueError(f"pairwise must be 'all' or 'subset', got {pairwise}")
+        if pairwise == "subset" and (subset_pairs is None or subset_pairs <= 0):
+            raise ValueError("subset_pairs must be a positive integer when pairwise='subset'")
+        self.names, self.channels, self.deltas = [], [], []
+        for name, m in attribute_latent_mapping.items():
+            if str(name).startswith("_"):
+                continue
+            ch = int(m["latent_channel"])
+            if latent_channels is not None and ch >= latent_channels:
+                raise ValueError(f"Latent channel {ch} for attribute {name} exceeds latent size {latent_channels}")
+            delta = m.get("delta")
+            if delta is None and delta_global and delta_global.get("enabled", False):
+                delta = delta_global.get("value")
+            if delta is None:
+                raise ValueError(f"Delta not provided for {name} and no delta_global fallback.")
+            self.names.append(name)
+            self.channels.append(ch)
+            self.deltas.append(float(delta))
+        if not self.names:
+            raise ValueError("attribute_latent_mapping must be provided when AR-VAE is enabled.")
+        self.gamma, self.pairwise, self.subset_pairs = float(gamma), pairwise, subset_pairs
+
+    @classmethod
+    def from_config(cls, regularized_attributes: dict, gamma: float, latent_channels: int | None = None):
+        ra = regularized_attributes or {}
+        return cls(ra.get("attribute_latent_mapping", {}), gamma=gamma, pairwise=ra.get("pairwise", "all"),
+                   subset_pairs=ra.get("subset_pairs"), delta_global=ra.get("delta_global", {}),
+                   latent_channels=latent_channels)
+
+
 class VAETrainer:
     def __init__(self, model, *, lr: float, world_size: int = 1, process_group=None, recon_loss: str = "l1",
                  kl_weight: float = 1e-3, kl_input_is_logvar: bool = True, bucket_bytes: int = 4 << 20,
-                 rank_eps_offset: int = 0):
+                 rank_eps_offset: int = 0, ar: ARSettings | None = None):
         self.model = model
         self.net = net = model.autoencoder
         self.eng = net.engine()
@@ -49,10 +130,55 @@ class VAETrainer:
         # the GPU always has the next step queued, the host never gets further ahead than that.
         self.max_steps_in_flight = int(os.environ.get("PTI_MAX_STEPS_IN_FLIGHT", "2"))
         self._step_done = collections.deque()
+        self.ar = ar
+        if ar is not None:
+            if max(ar.channels) >= net.latent_channels:
+                raise ValueError(f"AR-VAE latent channel {max(ar.channels)} exceeds latent size {net.latent_channels}")
+            dev = net.param_arena.device
+            self._ar_ch = torch.tensor(ar.channels, dtype=torch.int32, device=dev)
+            self._ar_delta = torch.tensor(ar.deltas, dtype=torch.float32, device=dev)
 
-    def step(self, images: torch.Tensor, eps: torch.Tensor | None = None):
+    # ---- AR-VAE term -------------------------------------------------------------------------------------------
+    def _ar_inputs(self, attributes, batch):
+        """[na, b] attribute table (mapping order) and, for pairwise="subset", the sampled-pair mask: Python
+        ``random.sample`` over the ordered pair list, one draw per attribute -- the reference's sampling (losses.py:132-136)."""
+        ar = self.ar
+        if attributes is None:
+            raise ValueError("AR-VAE is enabled but attributes are missing from the batch.")
+        rows = []
+        for name in ar.names:
+            a = attributes.get(name)
+            if a is None:
+                raise KeyError(f"Missing attribute values for {name} in batch.")
+            rows.append(a.to(self._ar_delta.device, torch.float32).reshape(-1))
+        table = torch.stack(rows, 0).contiguous()
+        if table.shape[1] != batch:
+            raise ValueError(f"attributes hold {table.shape[1]} values per name for a batch of {batch}")
+        mask = None
+        if ar.pairwise == "subset":
+            pairs = [(i, j) for i in range(batch) for j in range(batch) if i != j]
+            m = torch.zeros(len(ar.names), batch, batch, dtype=torch.uint8)
+            for q in range(len(ar.names)):
+                for i, j in random.sample(pairs, min(len(pairs), int(ar.subset_pairs))):
+                    m[q, i, j] = 1
+            mask = m.to(table.device)
+        return table, mask
+
+    def _ar_term(self, mu, attributes, d_mu):
+        """-> (sum of the per-attribute losses, per-attribute losses [na], pair counts [na]) as device tensors; adds
+        gamma * gradient into ``d_mu`` when given."""
+        table, mask = self._ar_inputs(attributes, mu.shape[0])
+        na = table.shape[0]
+        per = torch.empty(na, dtype=torch.float32, device=mu.device)
+        cnt = torch.empty(na, dtype=torch.int32, device=mu.device)
+        ops.ar_vae_loss(mu, table, self._ar_ch, self._ar_delta, per, cnt, gamma=self.ar.gamma, d_mu=d_mu, pair_mask=mask)
+        return per.sum(), per, cnt
+
+    def step(self, images: torch.Tensor, eps: torch.Tensor | None = None, attributes: dict | None = None):
         """One optimiser step on ``images`` [B,C,H,W] fp32 (already on the device).  Returns a dict of
-        DEVICE scalars {"loss", "recon", "kl"} (no host sync with THIS step; see ``max_steps_in_flight``)."""
+        DEVICE scalars {"loss", "recon", "kl"} -- plus {"ar", "ar_per_attr", "ar_pairs"} (names: ``self.ar.names``) when
+        the AR-VAE term is on, which needs ``attributes`` = {name: [B] tensor} -- with no host sync with THIS step
+        (see ``max_steps_in_flight``)."""
         net, eng, red = self.net, self.eng, self.reducer
         while len(self._step_done) >= max(1, self.max_steps_in_flight):
             self._step_done.popleft().synchronize()
@@ -70,6 +196,9 @@ class VAETrainer:
             d_recon, d_mu, d_third = torch.empty_like(recon), torch.empty_like(mu), torch.empty_like(third)
             ops.vae_loss(recon, images.contiguous().float(), mu, third, out2, d_recon, d_mu, d_third, l2=self.l2,
                          third_mode=self.third_mode, kl_weight=self.kl_weight)
+            ar_out = None
+            if self.ar is not None:   # + gamma * AR-VAE(z_mu.mean(h, w)): its gradient goes straight into d_mu
+                ar_out = self._ar_term(mu, attributes, d_mu)
             dz = eng.decode_backward(c_dec, d_recon, want_dz=True, join=False)   # encode_backward joins the side stream
             # z = mu + eps*sigma ; third = sigma (or 2 log sigma)
             d_sigma = d_third if net.third_output == "sigma" else d_third * (2.0 / sigma)
@@ -83,12 +212,17 @@ class VAETrainer:
         done = torch.cuda.Event()
         done.record()
         self._step_done.append(done)
-        return {"loss": out2[0] + self.kl_weight * out2[1], "recon": out2[0], "kl": out2[1]}
+        res = {"loss": out2[0] + self.kl_weight * out2[1], "recon": out2[0], "kl": out2[1]}
+        if ar_out is not None:
+            res["ar"], res["ar_per_attr"], res["ar_pairs"] = ar_out
+            res["loss"] = res["loss"] + self.ar.gamma * ar_out[0]
+        return res
 
     @torch.no_grad()
-    def eval_losses(self, images: torch.Tensor):
+    def eval_losses(self, images: torch.Tensor, attributes: dict | None = None):
         """Validation forward as the reference does it (``validate``: SAMPLED forward under no_grad,
-        train_vae.py:555-560).  Returns device scalars {"recon", "kl"} and the reconstruction."""
+        train_vae.py:555-560; AR-VAE term :573-589).  Returns device scalars {"recon", "kl"[, "ar", ...]} and the
+        reconstruction."""
         mu, sigma, _ = self.eng.encode_forward(images, save=False)
         eps = torch.randn(sigma.shape, generator=self.gen, device=sigma.device, dtype=sigma.dtype)
         recon, _ = self.eng.decode_forward(torch.addcmul(mu, eps, sigma), save=False)
@@ -96,4 +230,7 @@ class VAETrainer:
         out2 = torch.zeros(2, dtype=torch.float32, device=recon.device)
         ops.vae_loss(recon, images.contiguous().float(), mu, third, out2, None, None, None, l2=self.l2,
                      third_mode=self.third_mode, kl_weight=self.kl_weight)
-        return {"recon": out2[0], "kl": out2[1]}, recon
+        res = {"recon": out2[0], "kl": out2[1]}
+        if self.ar is not None:
+            res["ar"], res["ar_per_attr"], res["ar_pairs"] = self._ar_term(mu, attributes, None)
+        return res, recon

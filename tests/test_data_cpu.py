@@ -111,3 +111,55 @@ def test_oracle_normalisation_known_answers():
     big = np.arange(16, dtype=np.float32).reshape(4, 4)
     assert np.allclose(resize_area(big, (2, 2)), [[2.5, 4.5], [10.5, 12.5]])
     assert preprocess(big, (2, 2)).shape == (1, 2, 2)
+
+
+# ---- attribute join of the AR-VAE branch (reference data/dataloaders.py:108-221,432-465) --------------------------------
+def test_attribute_join_follows_the_path_split(tmp_path):
+    import json
+    import random
+    from pti_ldm_vae_amd.data.attributes import (attributes_for_paths, collate_with_attributes,
+                                                 filter_attributes_for_paths, select_attribute_sources)
+    from pti_ldm_vae_amd.data import split_paths
+    paths = [f"/data/edente/img_{i:03d}.tif" for i in range(10)]
+    table = {os.path.basename(p): {"height_0": float(i), "width_0": 10.0 * i, "unused": -1.0} for i, p in enumerate(paths)}
+    f = tmp_path / "attrs_edente.json"
+    f.write_text(json.dumps(table))
+    ra = {"attribute_file": str(f), "normalize_attributes": {"enabled": True, "divisor": 10.0},
+          "attribute_latent_mapping": {"_c": "comment", "height_0": {"latent_channel": 0}, "width_0": {"latent_channel": 1}}}
+    # the reference shuffles (path, attrs) PAIRS with random.seed(seed) (dataloaders.py:469-475); joining by basename after
+    # the path split must reproduce that pairing
+    attrs_sorted = attributes_for_paths(paths, ra, "edente")
+    random.seed(42)
+    paired = list(zip(paths, attrs_sorted))
+    random.shuffle(paired)
+    train_p, val_p = split_paths(paths, 0.8, seed=42)
+    assert [p for p, _ in paired[:8]] == train_p and [p for p, _ in paired[8:]] == val_p
+    assert attributes_for_paths(train_p, ra, "edente") == [a for _, a in paired[:8]]
+    assert attrs_sorted[3] == {"height_0": 0.3, "width_0": 3.0}            # filtered to the mapping, divided by 10
+    # "both": the source is inferred from the path, "edente" before "dente"
+    g = tmp_path / "attrs_dente.json"
+    g.write_text(json.dumps({"x.tif": {"height_0": 7.0, "width_0": 8.0}}))
+    src = select_attribute_sources({"edente": str(f), "dente": str(g)}, "both")
+    got = filter_attributes_for_paths(["/d/dente/x.tif", paths[2]], src, {"height_0": {}, "width_0": {}}, None)
+    assert got == [{"height_0": 7.0, "width_0": 8.0}, {"height_0": 2.0, "width_0": 20.0}]
+    with pytest.raises(FileNotFoundError, match="Attribute entry missing"):
+        filter_attributes_for_paths(["/d/dente/nope.tif"], src, {"height_0": {}}, None)
+    with pytest.raises(KeyError, match="Missing attributes"):
+        filter_attributes_for_paths(["/d/dente/x.tif"], src, {"depth": {}}, None)
+    with pytest.raises(ValueError, match="Cannot identify data source"):
+        filter_attributes_for_paths(["/d/other/x.tif"], src, {"height_0": {}}, None)
+    with pytest.raises(ValueError, match="divisor must be non-zero"):
+        filter_attributes_for_paths([paths[0]], src, {"height_0": {}}, {"enabled": True, "divisor": 0})
+    with pytest.raises(FileNotFoundError, match="Attribute file not found"):
+        select_attribute_sources(str(tmp_path / "missing.json"), "edente")
+    bad = tmp_path / "bad.json"
+    bad.write_text("{not json")
+    with pytest.raises(ValueError, match="Invalid attribute JSON"):
+        select_attribute_sources(str(bad), "edente")
+    with pytest.raises(ValueError, match="must be a string or mapping"):
+        select_attribute_sources(3, "edente")
+    with pytest.raises(ValueError, match="attribute_latent_mapping must be provided"):
+        attributes_for_paths(paths, {"attribute_file": str(f)}, "edente")
+    import torch
+    ims, at = collate_with_attributes([(torch.zeros(1, 2, 2), {"a": 1, "b": 2.5}), (torch.ones(1, 2, 2), {"a": 3, "b": 4})])
+    assert ims.shape == (2, 1, 2, 2) and at["a"].dtype == torch.float32 and at["b"].tolist() == [2.5, 4.0]

@@ -94,3 +94,43 @@ def test_train_script_on_tiff_directory(dev, tmp_path):
     tl = [l["train/loss_total"] for l in lines if "train/loss_total" in l]
     assert len(tl) >= 4 and all(np.isfinite(tl)) and any("val/recon_loss" in l for l in lines)
     assert "autoencoder_last.pt" in os.listdir(tmp_path / "run" / "trained_weights")
+
+
+def test_train_script_ar_vae_on_tiff_directory_with_attribute_file(dev, tmp_path):
+    """The AR-VAE config path end to end: attribute JSON joined to the TIFF list, (images, attributes) batches from
+    the device loader, prepare_batch, the AR term inside the native step, AR metrics in the log."""
+    from pti_ldm_vae_amd import train_vae
+    from pti_ldm_vae_amd.data import create_vae_dataloaders
+    rng = np.random.default_rng(8)
+    base, _ = _write_dir(tmp_path, 12, rng)
+    names = sorted(os.listdir(os.path.join(base, "dente")))
+    table = {f: {"height_0": float(rng.random()), "width_0": float(rng.random()), "extra": 1.0} for f in names}
+    af = tmp_path / "attrs.json"
+    af.write_text(json.dumps(table))
+    ra = {"enabled": True, "attribute_file": str(af), "gamma": 0.5, "pairwise": "all",
+          "delta_global": {"enabled": True, "value": 2.0}, "normalize_attributes": {"enabled": False},
+          "attribute_latent_mapping": {"height_0": {"latent_channel": 0}, "width_0": {"latent_channel": 2, "delta": 1.0}}}
+    tr_l, va_l, tr_p, va_p = create_vae_dataloaders(base, 4, (64, 64), data_source="dente", num_workers=2, device=dev,
+                                                    ar_vae_enabled=True, regularized_attributes=ra)
+    tr_l.set_epoch(0)
+    images, attrs = next(iter(tr_l))
+    assert images.shape == (4, 1, 64, 64) and set(attrs) == {"height_0", "width_0"}
+    assert attrs["height_0"].is_cuda and attrs["height_0"].dtype == torch.float32 and attrs["height_0"].shape == (4,)
+    from pti_ldm_vae_amd.data import shard_indices
+    first = shard_indices(len(tr_p), 0, 1, True, 42, 0)[:4]
+    want = [table[os.path.basename(tr_p[i])]["height_0"] for i in first]
+    assert attrs["height_0"].cpu().tolist() == pytest.approx(want)
+    cfg = json.load(open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "config", "ar_vae_dente_kl1e3.json")))
+    cfg.update(run_dir=str(tmp_path / "run"), data_base_dir=base, data_source="dente", regularized_attributes=ra)
+    cfg["autoencoder_def"].update(channels=[32, 64], attention_levels=[False, False], num_res_blocks=1, norm_num_groups=16,
+                                  latent_channels=4)
+    cfg["autoencoder_train"].update(batch_size=4, patch_size=[64, 64], max_epochs=2, perceptual_weight=0.0, adv_enabled=False,
+                                    ar_vae_enabled=True, ar_vae_weight=0.5)
+    cf = tmp_path / "cfg.json"
+    cf.write_text(json.dumps(cfg))
+    train_vae.main(["-c", str(cf), "--log-every", "1", "--num-workers", "2"])
+    lines = [json.loads(l) for l in open(tmp_path / "run" / "metrics.jsonl")]
+    tl = [l for l in lines if "train/ar_loss_total" in l]
+    assert len(tl) >= 4 and all(np.isfinite(l["train/ar_loss_total"]) and l["train/ar_loss_total"] > 0 for l in tl)
+    assert tl[0]["train/ar_pairs_height_0"] == 12 and tl[0]["train/ar_delta_height_0"] == 2.0 and tl[0]["train/ar_delta_width_0"] == 1.0
+    assert any("val/ar_loss_total" in l for l in lines)

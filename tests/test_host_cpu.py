@@ -181,3 +181,46 @@ def test_flat_adam_state_dict_is_torch_adam_compatible():
     for n, (o, cnt, _) in m.autoencoder._slots.items():
         used[o:o + cnt] = True
     assert torch.all(opt2.exp_avg[used] == 0.5) and torch.all(opt2.exp_avg_sq[used] == 0.25)
+
+
+# ---- _prepare_batch container forms (reference vae_scripts/train_vae.py:183-243) --------------------------------------
+def test_prepare_batch_container_forms():
+    from pti_ldm_vae_amd.trainer import prepare_batch
+    dev = torch.device("cpu")
+    x = torch.randn(3, 1, 4, 4)
+    attrs = {"h": torch.tensor([1.0, 2.0, 3.0]), "w": torch.tensor([4.0, 5.0, 6.0])}
+    im, a = prepare_batch(x, dev, False)                                   # plain tensor
+    assert im is x or torch.equal(im, x)
+    assert a is None
+    im, a = prepare_batch((x, attrs), dev, True)                           # collate_with_attributes output
+    assert torch.equal(im, x) and torch.equal(a["w"], attrs["w"])
+    im, a = prepare_batch([x, attrs], dev, True)                           # [images, dict]
+    assert torch.equal(im, x) and set(a) == {"h", "w"}
+    pairs = [(x[i], {"h": float(i), "w": 2.0 * i}) for i in range(3)]      # un-stacked list of (image, attrs)
+    im, a = prepare_batch(pairs, dev, True)
+    assert im.shape == x.shape and a["h"].dtype == torch.float32 and a["w"].tolist() == [0.0, 2.0, 4.0]
+    im, a = prepare_batch([(x[0], None), (x[1], None)], dev, False)        # pairs without attributes
+    assert im.shape == (2, 1, 4, 4) and a is None
+    with pytest.raises(ValueError, match="Empty batch"):
+        prepare_batch([], dev, False)
+    with pytest.raises(ValueError, match="attributes are missing"):
+        prepare_batch(x, dev, True)
+    with pytest.raises(TypeError, match="Unsupported list batch"):
+        prepare_batch([x, x, x], dev, False)
+    with pytest.raises(TypeError, match="Unsupported batch type"):
+        prepare_batch({"images": x}, dev, False)
+
+
+def test_ar_settings_validation():
+    from pti_ldm_vae_amd.trainer import ARSettings
+    mp = {"_comment": "x", "h": {"latent_channel": 1, "delta": 2.0}, "w": {"latent_channel": 0}}
+    st = ARSettings(mp, gamma=0.5, delta_global={"enabled": True, "value": 3.0})
+    assert st.names == ["h", "w"] and st.channels == [1, 0] and st.deltas == [2.0, 3.0]
+    with pytest.raises(ValueError, match="Delta not provided"):
+        ARSettings(mp, gamma=0.5)
+    with pytest.raises(ValueError, match="exceeds latent size"):
+        ARSettings(mp, gamma=0.5, delta_global={"enabled": True, "value": 3.0}, latent_channels=1)
+    with pytest.raises(ValueError, match="pairwise must be"):
+        ARSettings(mp, gamma=0.5, pairwise="some")
+    with pytest.raises(ValueError, match="subset_pairs"):
+        ARSettings(mp, gamma=0.5, pairwise="subset")
