@@ -1,0 +1,96 @@
+"""Worker of tests/test_gpu_data_parallel.py: ONE rank of a world-size-2 data-parallel job whose ranks share cuda:0
+(gloo process group; the one-GPU box has no second card, and RCCL needs one device per rank).  Launched by
+``python -m torch.distributed.run`` from a process that has not touched the GPU (tests/conftest.py).
+
+Each rank runs the NATIVE trainer (``VAETrainer.step``: HIP forward / backward, weight gradients on the side stream,
+``grad_ready_cb`` -> ``FlatGradAllReducer.ready`` enqueued behind that stream, ``finish()`` before Adam) on ITS half of a
+fixed batch and rank 0 writes what the test checks: the all-reduced gradient arena, the parameters after the step,
+the list of buckets the reducer launched.  Then the drop-in path: the same model wrapped in
+``DistributedDataParallel(..., find_unused_parameters=True)`` exactly as the reference wraps it (train_vae.py:282),
+one forward / backward through autograd; rank 0 writes the DDP-averaged gradients."""
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+CFG = dict(spatial_dims=2, in_channels=1, out_channels=1, latent_channels=4, channels=[32, 64, 128], num_res_blocks=1,
+           norm_num_groups=16, norm_eps=1e-6, attention_levels=[False, False, False], with_encoder_nonlocal_attn=True,
+           with_decoder_nonlocal_attn=True)
+BATCH, SIZE, LR, SEED = 4, 64, 1e-4, 1234
+
+
+def fixed_inputs():
+    g = torch.Generator().manual_seed(SEED)
+    x = torch.randn(BATCH, 1, SIZE, SIZE, generator=g)
+    eps = torch.randn(BATCH, 4, SIZE // 4, SIZE // 4, generator=g)
+    return x, eps
+
+
+def build_model(dev):
+    from pti_ldm_vae_amd.models import VAEModel
+    torch.manual_seed(SEED)
+    return VAEModel.from_config(CFG).to(dev)
+
+
+def main(outdir):
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group(backend="gloo", init_method="env://")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    from pti_ldm_vae_amd.models import compute_kl_loss
+    from pti_ldm_vae_amd.trainer import VAETrainer
+    x, eps = fixed_inputs()
+    lo, hi = rank * BATCH // world, (rank + 1) * BATCH // world
+    xs, es = x[lo:hi].to(dev), eps[lo:hi].to(dev)
+
+    # ---- native trainer, side stream ON (the default), tiny buckets so that several go out during backward ----
+    model = build_model(dev)
+    if rank == 1:                      # the constructor's broadcast must bring every rank to rank 0's weights
+        with torch.no_grad():
+            model.autoencoder.param_arena.add_(0.5)
+    tr = VAETrainer(model, lr=LR, world_size=world, bucket_bytes=256 << 10)
+    assert tr.eng.wgrad_stream is not None, "the side stream must be on for this test"
+    out = tr.step(xs, es)
+    torch.cuda.synchronize()
+    ae = model.autoencoder
+    launched = sorted(tr.reducer.launched)
+    res = {"rank": rank, "loss": out["loss"].item(), "launched": launched, "arena_len": ae.grad_arena.numel()}
+    if rank == 0:
+        torch.save({"grad_sum": ae.grad_arena.detach().cpu(), "params": ae.param_arena.detach().cpu()},
+                   os.path.join(outdir, "native_rank0.pt"))
+    # every rank must hold the same reduced gradients and the same parameters afterwards
+    chk = torch.stack([ae.grad_arena.double().sum(), ae.param_arena.double().sum()]).cpu()
+    both = [torch.zeros_like(chk) for _ in range(world)]
+    dist.all_gather(both, chk)
+    res["ranks_agree"] = bool(torch.equal(both[0], both[1]))
+
+    # ---- drop-in path under DistributedDataParallel(find_unused_parameters=True), as train_vae.py:282 wraps it ----
+    try:
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        m2 = build_model(dev)
+        ddp = DDP(m2, device_ids=[0], find_unused_parameters=True)
+        rec, mu, sig = ddp(xs)            # sampled forward (device RNG): only gradient CONSISTENCY is checked here
+        loss = torch.nn.functional.l1_loss(rec, xs) + 1e-3 * compute_kl_loss(mu, sig)
+        loss.backward()
+        torch.cuda.synchronize()
+        g = torch.cat([p.grad.detach().flatten() for p in m2.parameters()])
+        s = torch.stack([g.double().sum(), g.double().abs().sum()]).cpu()
+        both = [torch.zeros_like(s) for _ in range(world)]
+        dist.all_gather(both, s)
+        res["ddp"] = {"ok": True, "finite": bool(torch.isfinite(g).all()), "ranks_agree": bool(torch.equal(both[0], both[1])),
+                      "grad_abs_sum": float(s[1])}
+    except Exception as ex:   # reported, the test decides
+        res["ddp"] = {"ok": False, "error": repr(ex)}
+    with open(os.path.join(outdir, f"rank{rank}.json"), "w") as f:
+        json.dump(res, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
