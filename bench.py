@@ -91,6 +91,134 @@ def cpu_baseline(cfg_def, size, batch, steps):
                       f"reference's torch.set_num_threads(4)"}
 
 
+def roofline_from_profile(rec, steps):
+    """Aggregate ops.KERNEL_PROFILE records (name, flops, bytes, start, end) of ``steps`` instrumented steps into the
+    ``roofline`` object: dominant kernel by time, bound chosen by its algorithmic intensity against the machine balance."""
+    roofline = None
+    if True:
+        agg = {}
+        for name, flops, nbytes, e0, e1 in rec:
+            a = agg.setdefault(name, [0.0, 0.0, 0.0, 0])
+            a[0] += e0.elapsed_time(e1) * 1e-3
+            a[1] += flops
+            a[2] += nbytes
+            a[3] += 1
+        if agg:
+            name, (tsec, flops, nbytes, cnt) = max(agg.items(), key=lambda kv: kv[1][0])
+            # which roof bounds the dominant kernel: its algorithmic intensity against the machine balance
+            intensity = flops / nbytes
+            hbm_bound = intensity < PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+            tfl, gbs = flops / tsec / 1e12, nbytes / tsec / 1e9
+            traffic = None   # HBM bytes per launch from the separate rocprofv3 --pmc passes committed under profiles/
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)))["kernels"].get(name)
+                if pmc:
+                    traffic = pmc["fetch_bytes"] + pmc["write_bytes"]
+            except (OSError, ValueError, KeyError):
+                pass
+            roofline = {"kernel": name, "bound": "hbm" if hbm_bound else "mfma",
+                        "achieved": round(gbs if hbm_bound else tfl, 2),
+                        "peak": PEAK_HBM_GBS if hbm_bound else PEAK_BF16_TFLOPS,
+                        "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                        "frac": round(gbs / PEAK_HBM_GBS if hbm_bound else tfl / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                        "traffic_source": f"profiles/{PMC_TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, avg per launch)",
+                        "algorithmic_bytes_per_launch": round(nbytes / cnt),
+                        "algorithmic_gflop_per_launch": round(flops / cnt / 1e9, 3),
+                        "flop_per_byte": round(intensity, 1),
+                        "launches_per_step": cnt // steps, "avg_launch_us": round(tsec / cnt * 1e6, 2),
+                        "algorithmic_tflops": round(tfl, 1), "algorithmic_hbm_gbs": round(gbs, 1),
+                        "all_mfma_kernels": {k: {"ms_per_step": round(v[0] / steps * 1e3, 3),
+                                                 "tflops": round(v[1] / v[0] / 1e12, 1),
+                                                 "gbs": round(v[2] / v[0] / 1e9), "launches": v[3] // steps}
+                                             for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}}
+    return roofline
+
+
+def bench_regression(args, cfg, dev, world, rank, dist):
+    """config/reg_edente_from_dente.json: one step = the body of the reference's ``train_one_epoch``
+    (regression_utils.py:318-347): frozen-encoder forward under no_grad (HIP engine, 17.66 GFLOP per 256x256 image) ->
+    flatten -> MLP head -> MSE -> backward through the head -> Adam on the head.  N > 1: one encoder replica per GPU and a
+    SUM all-reduce of the head's 1.06 M gradients (4.2 MB) per step.  Random-init encoder (no checkpoint offline)."""
+    import torch.distributed as d
+    from pti_ldm_vae_amd import ops
+    from pti_ldm_vae_amd.models import VAEModel
+    from pti_ldm_vae_amd.utils import regression_utils as R
+    from pti_ldm_vae_amd.utils.config import load_vae_config
+    vae_cfg_path = cfg["vae"]["config_file"]
+    if not os.path.isabs(vae_cfg_path):
+        vae_cfg_path = os.path.join(ROOT, vae_cfg_path)
+    cfg_def = load_vae_config(vae_cfg_path).autoencoder_def
+    data_cfg, tr = R.extract_regression_data_config(cfg), R.extract_regression_train_config(cfg)
+    size = args.size
+    cfg["data"] = dict(data_cfg, patch_size=[size, size])
+    targets = list(cfg["targets"])
+    torch.manual_seed(42)
+    vae = VAEModel.from_config(cfg_def).to(dev).eval()
+    model, latent_dim = R.build_regression_model(vae, cfg, targets, dev)
+    head_params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(head_params, lr=tr["lr"] * world)
+    loss_fn = R.build_loss_fn(tr["loss"])
+    images = synthetic_batch(args.batch, cfg_def["in_channels"], size, dev, seed=42 + rank)
+    y = torch.rand(args.batch, len(targets), generator=torch.Generator(device=dev).manual_seed(7 + rank), device=dev)
+
+    def step():
+        opt.zero_grad()
+        loss = loss_fn(model(images), y)
+        loss.backward()
+        if world > 1:
+            flat = torch.cat([p.grad.flatten() for p in head_params])
+            d.all_reduce(flat)
+            o = 0
+            for p in head_params:
+                p.grad.copy_(flat[o:o + p.numel()].view_as(p) / world)
+                o += p.numel()
+        opt.step()
+        return loss
+
+    def sync_all():
+        if world > 1:
+            d.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        d.all_reduce(t, op=d.ReduceOp.MAX)
+        dt = float(t.item())
+    roofline = None
+    if rank == 0:
+        ops.KERNEL_PROFILE = []
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    if rank == 0:
+        rec, ops.KERNEL_PROFILE = ops.KERNEL_PROFILE, None
+        roofline = roofline_from_profile(rec, 2)
+        enc_gflop = 17.66 * (size / 256.0) ** 2 if tuple(cfg_def["channels"]) == (32, 64, 128, 128) else None
+        value = args.batch * world * args.steps / dt
+        line = {"metric": "vae_encoder_regression_images_per_sec_256x256_bf16", "value": round(value, 2), "unit": "images/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": f"config/{os.path.basename(args.config)} {size}x{size}x{cfg_def['in_channels']} batch "
+                                       f"{args.batch}/GPU: frozen-encoder forward (no_grad, random-init VAE of "
+                                       f"{os.path.basename(vae_cfg_path)}) + MLP head {latent_dim}->"
+                                       f"{'->'.join(str(h) for h in cfg['regressor_def']['hidden_dims'])}->{len(targets)} fwd/bwd + Adam",
+                           "global_batch": args.batch * world, "parallelism": f"dp{world}", "final_loss": round(float(loss.item()), 5)},
+                "model_tflops_per_gpu": round(value / world * enc_gflop / 1e3, 1) if enc_gflop else None,
+                "frac_of_mfma_peak_end_to_end": round(value / world * enc_gflop / 1e3 / PEAK_BF16_TFLOPS, 4) if enc_gflop else None,
+                "roofline": roofline}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        d.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -125,6 +253,8 @@ def main():
     torch.cuda.set_device(dev)
 
     cfg = read_config(args.config)
+    if "regressor_def" in cfg or "regression_train" in cfg:      # BASELINE config 5: regression on frozen latents
+        return bench_regression(args, cfg, dev, world, rank, dist)
     cfg_def = cfg["autoencoder_def"]
     tr = cfg["autoencoder_train"]
     torch.manual_seed(42)                       # set_determinism(args.seed), train_vae.py:808
@@ -187,41 +317,7 @@ def main():
     trainer.eng.wgrad_stream = side
     if rank == 0:
         rec, ops.KERNEL_PROFILE = ops.KERNEL_PROFILE, None
-        agg = {}
-        for name, flops, nbytes, e0, e1 in rec:
-            a = agg.setdefault(name, [0.0, 0.0, 0.0, 0])
-            a[0] += e0.elapsed_time(e1) * 1e-3
-            a[1] += flops
-            a[2] += nbytes
-            a[3] += 1
-        if agg:
-            name, (tsec, flops, nbytes, cnt) = max(agg.items(), key=lambda kv: kv[1][0])
-            # which roof bounds the dominant kernel: its algorithmic intensity against the machine balance
-            intensity = flops / nbytes
-            hbm_bound = intensity < PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
-            tfl, gbs = flops / tsec / 1e12, nbytes / tsec / 1e9
-            traffic = None   # HBM bytes per launch from the separate rocprofv3 --pmc passes committed under profiles/
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)))["kernels"].get(name)
-                if pmc:
-                    traffic = pmc["fetch_bytes"] + pmc["write_bytes"]
-            except (OSError, ValueError, KeyError):
-                pass
-            roofline = {"kernel": name, "bound": "hbm" if hbm_bound else "mfma",
-                        "achieved": round(gbs if hbm_bound else tfl, 2),
-                        "peak": PEAK_HBM_GBS if hbm_bound else PEAK_BF16_TFLOPS,
-                        "unit": "GB/s" if hbm_bound else "TFLOP/s",
-                        "frac": round(gbs / PEAK_HBM_GBS if hbm_bound else tfl / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                        "traffic_source": f"profiles/{PMC_TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, avg per launch)",
-                        "algorithmic_bytes_per_launch": round(nbytes / cnt),
-                        "algorithmic_gflop_per_launch": round(flops / cnt / 1e9, 3),
-                        "flop_per_byte": round(intensity, 1),
-                        "launches_per_step": cnt // 2, "avg_launch_us": round(tsec / cnt * 1e6, 2),
-                        "algorithmic_tflops": round(tfl, 1), "algorithmic_hbm_gbs": round(gbs, 1),
-                        "all_mfma_kernels": {k: {"ms_per_step": round(v[0] / 2 * 1e3, 3),
-                                                 "tflops": round(v[1] / v[0] / 1e12, 1),
-                                                 "gbs": round(v[2] / v[0] / 1e9), "launches": v[3] // 2}
-                                             for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}}
+        roofline = roofline_from_profile(rec, 2)
     if world > 1:
         dist.barrier()
 

@@ -92,13 +92,15 @@ class DeviceImageLoader:
 
     def __init__(self, paths: list[str], batch_size: int, patch_size: tuple[int, int], device, *, rank: int = 0,
                  world_size: int = 1, shuffle: bool = True, seed: int = 42, num_workers: int = 4,
-                 attributes: list[dict[str, float]] | None = None):
+                 attributes: list[dict[str, float]] | None = None, target_names: list[str] | None = None):
+        """``attributes``: one {name: value} dict per path; batches become ``(images, {name: [b] tensor})``.  With
+        ``target_names`` the values are instead stacked in that order: ``(images, [b, T] tensor)`` (regression)."""
         from .. import ops
         self._ops = ops
         self.paths, self.batch, self.patch = list(paths), int(batch_size), (int(patch_size[0]), int(patch_size[1]))
         if attributes is not None and len(attributes) != len(self.paths):
             raise ValueError("DeviceImageLoader: one attribute dict per image path is required")
-        self.attributes = attributes
+        self.attributes, self.target_names = attributes, target_names
         self.dev = torch.device(device)
         self.rank, self.world, self.shuffle, self.seed, self.epoch = rank, world_size, shuffle, seed, 0
         self.pool = ThreadPoolExecutor(max_workers=max(1, num_workers))
@@ -146,7 +148,7 @@ class DeviceImageLoader:
         slot["event"], slot["out"], slot["keep"] = ev, out, (desc, hw, d_off, d_hw)
         slot["attrs"] = None
         if self.attributes is not None:
-            names = list(self.attributes[idx[0]].keys())
+            names = self.target_names or list(self.attributes[idx[0]].keys())
             host = torch.tensor([[float(self.attributes[i][k]) for i in idx] for k in names], dtype=torch.float32).pin_memory()
             with torch.cuda.stream(self.copy_stream):
                 dev_attrs = host.to(self.dev, non_blocking=True)
@@ -176,7 +178,16 @@ class DeviceImageLoader:
             else:
                 names, table = cur["attrs"]
                 table.record_stream(torch.cuda.current_stream(self.dev))
-                yield cur["out"], {k: table[i] for i, k in enumerate(names)}
+                if self.target_names is not None:
+                    yield cur["out"], table.t().contiguous()
+                else:
+                    yield cur["out"], {k: table[i] for i, k in enumerate(names)}
+
+    def stacked_targets(self) -> torch.Tensor:
+        """[n, T] fp32 (host) targets of the whole set in path order (``DatasetWithTargets.stacked_targets``)."""
+        if self.attributes is None or self.target_names is None:
+            raise ValueError("Dataset must expose stacked_targets() to compute normalization statistics.")
+        return torch.tensor([[float(a[k]) for k in self.target_names] for a in self.attributes], dtype=torch.float32)
 
 
 def create_vae_dataloaders(data_base_dir: str, batch_size: int, patch_size: tuple[int, int], rank: int = 0,
@@ -207,4 +218,34 @@ def create_vae_dataloaders(data_base_dir: str, batch_size: int, patch_size: tupl
                               num_workers=num_workers, attributes=train_attrs)
     val = DeviceImageLoader(val_paths, batch_size, patch_size, device, rank=r, world_size=world, shuffle=False, seed=s,
                             num_workers=num_workers, attributes=val_attrs)
+    return train, val, train_paths, val_paths
+
+
+def create_regression_dataloaders(data_base_dir: str, attributes_path, targets: list[str], batch_size: int,
+                                  patch_size: tuple[int, int], train_split: float = 0.9, num_workers: int = 4,
+                                  seed: int | None = 42, subset_size: int | None = None, val_dir: str | None = None,
+                                  cache_rate: float = 0.0, data_source: str = "edente",
+                                  normalize_attributes: dict | None = None, rank: int = 0, device="cuda"):
+    """The reference's ``create_regression_dataloaders`` (dataloaders.py:596-740) on the device input pipeline:
+    ``(train_loader, val_loader, train_paths, val_paths)``; batches are ``(images [b,1,Hp,Wp], targets [b,T])`` device
+    tensors in ``targets`` order.  The train loader shuffles (the reference builds it with ``shuffle=True``)."""
+    from .attributes import filter_attributes_for_paths, select_attribute_sources
+    if not 0 < train_split < 1:
+        raise ValueError(f"train_split must be in (0, 1), got {train_split}")
+    if not 0.0 <= cache_rate <= 1.0:
+        raise ValueError(f"cache_rate must be in [0, 1], got {cache_rate}")
+    if len(targets) == 0:
+        raise ValueError("targets must contain at least one entry.")
+    paths = list_tif_paths(data_base_dir, data_source)
+    val_list = list_tif_paths(val_dir, data_source) if val_dir is not None else None
+    train_paths, val_paths = split_paths(paths, train_split, seed, subset_size, val_list)
+    sources = select_attribute_sources(attributes_path, data_source)
+    mapping = {t: t for t in targets}
+    tr_attrs = filter_attributes_for_paths(train_paths, sources, mapping, normalize_attributes)
+    va_attrs = filter_attributes_for_paths(val_paths, sources, mapping, normalize_attributes)
+    s = seed if seed is not None else 0
+    train = DeviceImageLoader(train_paths, batch_size, patch_size, device, shuffle=True, seed=s, num_workers=num_workers,
+                              attributes=tr_attrs, target_names=list(targets))
+    val = DeviceImageLoader(val_paths, batch_size, patch_size, device, shuffle=False, seed=s, num_workers=num_workers,
+                            attributes=va_attrs, target_names=list(targets))
     return train, val, train_paths, val_paths
