@@ -152,7 +152,8 @@ int pti_conv_wgrad_mfma(const void* x, const void* dy, const int64_t* in_stats, 
                         int64_t workspace_bytes, int accumulate, const pti_conv_desc* d,
                         pti_stream_t s);
 /* The same work as two calls (pti_conv_wgrad_mfma is exactly partials + reduce): the split-K partial launch,
- * which reports the number of slabs it wrote, and the fixed-order slab reduction into dw / dbias.  Lets a
+ * which reports in *splits_out an opaque slab token (slab count, plus a flag bit for the slab layout the kernel it
+ * picked writes), and the fixed-order slab reduction into dw / dbias, which takes that token as `splits`.  Lets a
  * caller time or overlap the two launches separately. */
 int pti_conv_wgrad_mfma_partials(const void* x, const void* dy, const int64_t* in_stats,
                                  const float* gamma, const float* beta, void* workspace,

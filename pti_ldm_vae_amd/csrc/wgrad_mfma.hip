@@ -16,6 +16,7 @@
 namespace {
 
 constexpr int TH = 8, TW = 16;
+constexpr int PTI_WGRAD_SLAB_V4 = 1 << 30;   // flag in the slab token of pti_conv_wgrad_mfma_partials: block-ordered slabs (v4)
 
 struct WgArgs {
   const bf16* x;
@@ -31,6 +32,7 @@ struct WgArgs {
   int ci_tiles;
   long long slab_stride;
   int x_f16;   // x is a forward activation stored fp16 (converted to the bf16 MFMA operand in the loader)
+  int diag;    // v4 tuning aid (PTI_WGRAD_V4_DIAG): 1 = no tile loads, 2 = no MFMA loop, 3 = neither (results are garbage)
 };
 
 template <int KS, int S_, int CO_T, int CI_T>
@@ -500,6 +502,307 @@ void wgrad_mfma3_kernel(WgArgs a) {   // COB 1: 3 waves/SIMD (<= 168 VGPR+AGPR),
   }
 }
 
+// =============================================================================================
+// v4 (3x3, PTI_CONV_S1, bf16 x without prologue -- the training step's saved activated inputs): 32co x 32ci block
+// per workgroup like v3, but
+//   * the x halo / dy tiles arrive by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass) into
+//     a ring of four PAIRS of stages, three pairs (six tiles, 120 KB) ahead, behind a COUNTED s_waitcnt vmcnt + ONE raw
+//     s_barrier per pair.  The DMA is issued from inline asm: through the builtin hipcc drains vmcnt(0) in front of
+//     the next LDS read (it cannot prove that the DMA's ring slot differs from the one being read), which serialises
+//     the ring -- the reason an earlier LDS-DMA variant of v3 measured no gain;
+//   * EIGHT waves = two groups of four; per iteration group g takes tile 2*it + g of this workgroup's split, wave w of
+//     a group the output rows 2w, 2w+1 of that 8x16 tile with all nine taps (144 accumulator registers): 18 MFMAs and
+//     28 transposing LDS reads per wave and tile, two waves per SIMD on all four SIMDs (v3's three kernel-column waves
+//     left one SIMD without MFMA work); the eight partial blocks are summed through LDS once, at the end, in a fixed
+//     order;
+//   * ONE workgroup per CU (the ring is the latency hiding) => S = 256 / (co,ci blocks) pixel splits instead of
+//     1024..1280 workgroups: 256 x 37 KB = 9.4 MB of partial slabs per launch instead of 38..47 MB (which exceeded the
+//     17 MB of x + dy of the 128-channel 32^2 layers more than twice, written AND re-read);
+//   * out-of-image halo pixels / ragged tile edges / tiles past the end read a 16-byte zero page, so every wave issues
+//     exactly 5 DMA instructions per iteration and the vmcnt arithmetic is uniform; interior tiles (no edge in reach)
+//     skip the per-piece range checks;
+//   * dbias rides the MFMA pipe: dy fragments times a fragment of ones (no VALU, no extra LDS traffic).
+// Stage image: [x: 12 x 1 KiB = 768 pieces (720 used: 10 x 18 halo pixels x 4 pieces)][dy: 8 KiB = 128 pixels x 4].
+// =============================================================================================
+__device__ __attribute__((aligned(16))) unsigned int pti_wgrad_zero_page[4] = {0u, 0u, 0u, 0u};
+
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+constexpr int W4_STG = 20 * 1024, W4_DP = 3, W4_NSTAGE = 2 * (W4_DP + 1), W4_IMG = 9 * 32 * 32 * 4;   // DP = pairs of tiles ahead
+constexpr int W4_LDS = (W4_NSTAGE * W4_STG > 4 * W4_IMG + 1024) ? W4_NSTAGE * W4_STG : 4 * W4_IMG + 1024;
+
+__global__ __launch_bounds__(512, 1) void wgrad_mfma4_kernel(WgArgs a) {
+  constexpr int HWp = TW + 2, NPX = 10 * HWp, PP = 64, XB = 12 * 1024, STG = W4_STG, DP = W4_DP, NPS = DP + 1;   // NPS pair slots
+  static_assert(W4_LDS <= 160 * 1024 && 5 * (DP - 1) <= 63, "ring must fit the LDS and the vmcnt counter");
+  typedef short v4s __attribute__((ext_vector_type(4)));
+  typedef short v8s __attribute__((ext_vector_type(8)));
+  __shared__ __attribute__((aligned(16))) unsigned char smem[W4_LDS];
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = w8 >> 2, w = w8 & 3;
+  int split, cc;   // XCD-aware block order (see v3)
+  {
+    const int id = blockIdx.x, tiles_cc = a.ci_tiles * (a.Cout / 32);
+    if (a.S >= 8) {
+      const int k = id >> 3;
+      cc = k % tiles_cc;
+      split = (k / tiles_cc) * 8 + (id & 7);
+    } else {
+      cc = id / a.S;
+      split = id % a.S;
+    }
+  }
+  const int cot = cc / a.ci_tiles, cit = cc % a.ci_tiles;
+  const int co0 = cot * 32, ci0 = cit * 32;
+  const bool do_bias = (cit == 0);   // block-uniform
+
+  // ---- DMA slots of this lane: 3 x pieces (instructions w, w+4, w+8 of the stage) and 2 dy pieces (w, w+4) ----
+  int xhy[3], xhx[3], xrel[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int i = (w + 4 * k) * 64 + lane, p = i >> 2;
+    xhy[k] = p < NPX ? p / HWp : 1 << 20;                    // pad pieces: never in range
+    xhx[k] = p - (p / HWp) * HWp;
+    xrel[k] = ((xhy[k] - 1) * a.W + xhx[k] - 1) * a.Cin * 2 + (ci0 + (i & 3) * 8) * 2;   // bytes from pixel (oy0, ox0) of sample n
+  }
+  int dty[2], dtx[2], drel[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int i = (w + 4 * k) * 64 + lane, p = i >> 2;
+    dty[k] = p >> 4;
+    dtx[k] = p & 15;
+    drel[k] = (dty[k] * a.Wo + dtx[k]) * a.Cout * 2 + (co0 + (i & 3) * 8) * 2;
+  }
+  const unsigned char* xb = reinterpret_cast<const unsigned char*>(a.x);
+  const unsigned char* db = reinterpret_cast<const unsigned char*>(a.dy);
+  const unsigned char* zero = reinterpret_cast<const unsigned char*>(pti_wgrad_zero_page);
+
+  // One DMA slot (k = 0..2: x pieces, 3..4: dy pieces) of tile `tile` into `stage`; tiles past the end read zeros so
+  // that every wave issues exactly 5 DMA instructions per iteration (uniform vmcnt arithmetic).
+  struct TilePos { const unsigned char* xt; const unsigned char* dt; int oy0, ox0; bool live, interior; };
+  auto locate = [&](int tile) -> TilePos {
+    TilePos tp;
+    tp.live = tile < a.ntiles;                                // wave-uniform
+    int t = tp.live ? tile : 0;
+    const int tx_ = t % a.tiles_x; t /= a.tiles_x;
+    const int ty_ = t % a.tiles_y;
+    const int n = t / a.tiles_y;
+    tp.oy0 = ty_ * 8; tp.ox0 = tx_ * TW;
+    tp.xt = xb + ((size_t)(n * a.H + tp.oy0) * a.W + tp.ox0) * a.Cin * 2;
+    tp.dt = db + ((size_t)(n * a.Ho + tp.oy0) * a.Wo + tp.ox0) * a.Cout * 2;
+    tp.interior = tp.oy0 >= 1 && tp.ox0 >= 1 && tp.oy0 + 9 <= a.H && tp.ox0 + 17 <= a.W;
+    return tp;
+  };
+  auto issue_slot = [&](const TilePos& tp, int stage, int k) {   // k is a compile-time constant at every call site
+    if (a.diag & 1) return;                                   // tuning aid: no tile loads
+    const unsigned sbase = lds0 + stage * STG + w * 1024;
+    if (k < 3) {
+      bool ok = tp.live && xhy[k] < 16;
+      if (!tp.interior) {
+        const int vy = tp.oy0 - 1 + xhy[k], vx = tp.ox0 - 1 + xhx[k];
+        ok = ok && vy >= 0 && vy < a.H && vx >= 0 && vx < a.W;
+      }
+      glds16(ok ? tp.xt + xrel[k] : zero, sbase + k * 4096);
+    } else {
+      const int kk = k - 3;
+      bool ok = tp.live;
+      if (!tp.interior) ok = ok && tp.oy0 + dty[kk] < a.Ho && tp.ox0 + dtx[kk] < a.Wo;
+      glds16(ok ? tp.dt + drel[kk] : zero, sbase + XB + kk * 4096);
+    }
+  };
+  auto issue = [&](int tile, int stage) {
+    const TilePos tp = locate(tile);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) issue_slot(tp, stage, k);
+  };
+
+  f32x16 acc[3][3], accb;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    accb[r] = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) acc[kh][kw][r] = 0.f;
+  }
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const int fbase = (8 * (g >> 1) + q) * PP + (16 * (g & 1) + 4 * pp) * 2;   // transposed-read lane base (as v3)
+  bf16x8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
+
+  // tiles of this split: split, split + S, ...; iteration `it` handles the pair (2 it, 2 it + 1), group g its element g
+  const int ntl = a.ntiles > split ? (a.ntiles - split + a.S - 1) / a.S : 0;
+  const int npair = (ntl + 1) >> 1;
+#pragma unroll
+  for (int s = 0; s < DP; ++s) issue(split + (2 * s + grp) * a.S, 2 * s + grp);
+  // compute(pslot, ft, fstage): 18 (+2) MFMAs of this wave's two output rows of its group's tile in pair slot `pslot`;
+  // this wave's five DMA pieces of the future tile `ft` are issued BETWEEN the MFMA groups (one after each halo
+  // row, one at the end) instead of in front of them: a wave that queues behind a full memory pipe at a DMA
+  // instruction then has MFMAs in flight, and its SIMD partner keeps the matrix pipe busy meanwhile.
+  auto compute = [&](int pslot, const TilePos& ft, int fstage) {
+    const unsigned char* lA = smem + (2 * pslot + grp) * STG;
+    const unsigned char* lD = lA + XB;
+    bf16x8 dfr[2];
+#pragma unroll
+    for (int oi = 0; oi < 2; ++oi) {
+      const unsigned char* dptr = lD + fbase + (2 * w + oi) * TW * PP;
+      const v4s d0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(dptr));
+      const v4s d1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(dptr + 4 * PP));
+      const v8s td = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+      dfr[oi] = __builtin_bit_cast(bf16x8, td);
+    }
+    if (do_bias) {
+      accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfr[0], ones, accb, 0, 0, 0);
+      accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfr[1], ones, accb, 0, 0, 0);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {      // halo rows 2w .. 2w+3
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const unsigned char* aptr = lA + fbase + ((2 * w + rr) * HWp + kw) * PP;
+        const v4s a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(aptr));
+        const v4s a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(aptr + 4 * PP));
+        const v8s ta = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        const bf16x8 afr = __builtin_bit_cast(bf16x8, ta);
+#pragma unroll
+        for (int oi = 0; oi < 2; ++oi) {
+          const int kh = rr - oi;          // halo row 2w+rr = output row 2w+oi + kh
+          if (kh >= 0 && kh < 3) acc[kh][kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfr[oi], afr, acc[kh][kw], 0, 0, 0);
+        }
+      }
+      issue_slot(ft, fstage, rr);
+    }
+    issue_slot(ft, fstage, 4);
+  };
+  int ps = 0;                                   // pair slot of iteration `it`
+  for (int it = 0; it < npair; ++it) {
+    int fs = ps + DP;
+    fs = fs >= NPS ? fs - NPS : fs;
+    const int kf = 2 * (it + DP) + grp;
+    const TilePos ft = locate(kf < ntl ? split + kf * a.S : a.ntiles);
+    wait_vmcnt<5 * (DP - 1)>();           // this wave's 5 pieces of pair `it` have landed (younger pairs may fly)
+    __builtin_amdgcn_s_barrier();         // ... everyone's have, and everyone is done reading the slot refilled below
+    // (the second tile of an odd last pair is a tile past the end: all zeros, it adds nothing)
+    if (a.diag & 2) {                     // tuning aid: loads only
+#pragma unroll
+      for (int k = 0; k < 5; ++k) issue_slot(ft, 2 * fs + grp, k);
+    } else {
+      compute(ps, ft, 2 * fs + grp);
+    }
+    ps = ps + 1 == NPS ? 0 : ps + 1;
+  }
+  wait_vmcnt<0>();                        // the zero-page pieces of the tiles past the end
+  __syncthreads();                        // every wave is done with the ring: it becomes the reduction scratch
+
+  // ---- sum the eight waves' partial blocks in a fixed order and store the slab ----
+  // round 1: waves 4..7 -> images 0..3, waves 0..3 add;  round 2: waves 2,3 -> images 0,1, waves 0,1 add;
+  // round 3: waves 0,1 -> images 0,1, every thread adds the two and stores.
+  // Image = the block in the order [tap][ci][co quad ^ (ci & 7)][4 co]: a lane's four consecutive output channels
+  // (registers 4q .. 4q+3 of a 32x32 accumulator) are one 16-byte LDS access, conflict-free through the XOR; the slab
+  // keeps that order (block cc at cc * 9216 floats), wgrad_reduce4_kernel undoes it.
+  float* red = reinterpret_cast<float*>(smem);               // up to four fp32 images of 9216 floats
+  float* bred = red + 4 * 9216;                               // [8][32] bias partials (1 KiB behind the images)
+  const int ci = lane & 31, hsel = lane >> 5;
+  auto dump = [&](float* img) {
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4)
+          *(f32x4*)(img + (kh * 3 + kw) * 1024 + ci * 32 + (((2 * q4 + hsel) ^ (ci & 7)) << 2)) =
+              f32x4{acc[kh][kw][4 * q4], acc[kh][kw][4 * q4 + 1], acc[kh][kw][4 * q4 + 2], acc[kh][kw][4 * q4 + 3]};
+  };
+  auto gather = [&](const float* img) {
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const f32x4 v = *(const f32x4*)(img + (kh * 3 + kw) * 1024 + ci * 32 + (((2 * q4 + hsel) ^ (ci & 7)) << 2));
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[kh][kw][4 * q4 + j] += v[j];
+        }
+  };
+  if (do_bias && ci == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bred[w8 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel] = accb[r];
+  }
+  if (a.diag & 8) return;
+  if (!(a.diag & 4)) {
+    if (w8 >= 4) dump(red + (w8 - 4) * 9216);
+    __syncthreads();
+    if (w8 < 4) gather(red + w8 * 9216);
+    __syncthreads();
+    if (w8 == 2 || w8 == 3) dump(red + (w8 - 2) * 9216);
+    __syncthreads();
+    if (w8 < 2) gather(red + w8 * 9216);
+    __syncthreads();
+  }
+  if (w8 < 2 && !(a.diag & 32)) dump(red + w8 * 9216);
+  __syncthreads();
+  float* slab = a.slab + (size_t)split * a.slab_stride + (size_t)cc * 9216;
+  if (!(a.diag & 16))
+  for (int i4 = tid; i4 < 2304; i4 += 512)
+    *(f32x4*)(slab + i4 * 4) = *(const f32x4*)(red + i4 * 4) + *(const f32x4*)(red + 9216 + i4 * 4);
+  if (do_bias && tid < 32) {
+    float sm = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sm += bred[k * 32 + tid];
+    a.slab[(size_t)split * a.slab_stride + (size_t)9 * a.Cout * a.Cin + co0 + tid] = sm;
+  }
+}
+
+// Slab reduction of the v4 layout: slab s = [(co,ci) block cc][tap][ci][co quad ^ (ci & 7)][4 co] + Cout bias sums.
+// Same fixed-order scheme as wgrad_reduce_kernel (16 float4 columns x 16 slab groups per block).
+__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* __restrict__ slab, long long stride, int S,
+                                                            float* __restrict__ dw, float* __restrict__ dbias, int Cout,
+                                                            int Cin, int accumulate) {
+  __shared__ f32x4 red[16][16];
+  const long long total = (long long)9 * Cout * Cin;
+  const int col = threadIdx.x & 15, sg = threadIdx.x >> 4;
+  const long long e = ((long long)blockIdx.x * 16 + col) * 4;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+  if (e < total + Cout) {
+    int k = sg;
+    for (; k + 16 < S; k += 32) {
+      s0 += *(const f32x4*)(slab + (size_t)k * stride + e);
+      s1 += *(const f32x4*)(slab + (size_t)(k + 16) * stride + e);
+    }
+    if (k < S) s0 += *(const f32x4*)(slab + (size_t)k * stride + e);
+  }
+  red[sg][col] = s0 + s1;
+  __syncthreads();
+  if (sg == 0 && e < total + Cout) {
+    f32x4 sum = red[0][col];
+#pragma unroll
+    for (int g = 1; g < 16; ++g) sum += red[g][col];
+    if (e < total) {
+      const int cc = (int)(e / 9216), i = (int)(e % 9216);
+      const int ci_tiles = Cin / 32;
+      const int co0 = (cc / ci_tiles) * 32, ci0 = (cc % ci_tiles) * 32;
+      const int tap = i >> 10, ci = (i >> 5) & 31, cog = ((i >> 2) & 7) ^ (ci & 7);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const size_t o = ((size_t)(co0 + cog * 4 + j) * Cin + ci0 + ci) * 9 + tap;
+        dw[o] = accumulate ? dw[o] + sum[j] : sum[j];
+      }
+    } else if (dbias) {
+      const int co = (int)(e - total);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dbias[co + j] = accumulate ? dbias[co + j] + sum[j] : sum[j];
+    }
+  }
+}
+
 // dW[co][ci][tap] (=|+=) sum_s slab[s][tap][co][ci];  dbias[co] (=|+=) sum_s slab[s][KK*Cout*Cin + co]
 // block = 16 float4 columns (64 consecutive slab elements) x 16 slab groups: slabs are summed by 16 threads in
 // parallel (fixed order => deterministic), folded through LDS, and written by the first group.
@@ -584,6 +887,8 @@ extern "C" int pti_conv_wgrad_mfma_partials(const void* x, const void* dy, const
   a.slab = (float*)workspace;
   a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Ho = d->ho; a.Wo = d->wo; a.Cout = d->cout;
   a.mode = d->mode; a.prologue = d->prologue; a.groups = d->groups; a.eps = d->eps; a.x_f16 = d->in_f16;
+  static const int diag_env = getenv("PTI_WGRAD_V4_DIAG") ? atoi(getenv("PTI_WGRAD_V4_DIAG")) : 0;
+  a.diag = diag_env;
   a.inv_cnt = d->prologue != PTI_PRO_NONE ? 1.0f / ((float)(d->cin / d->groups) * (float)d->h * (float)d->w) : 0.f;
   a.tiles_x = cdiv(d->wo, TW); a.tiles_y = cdiv(d->ho, TH); a.ntiles = d->n * a.tiles_x * a.tiles_y;
   // Tile / split choice.  3x3 stride-1 gathers: the tap-split 32x32 kernel (v3, measured faster on every such
@@ -621,16 +926,33 @@ extern "C" int pti_conv_wgrad_mfma_partials(const void* x, const void* dy, const
   if (S < 1) S = 1;
   if (S > smax) S = (int)smax;
   if (S < 1) PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma: workspace too small (%lld bytes per split needed)", a.slab_stride * 4);
-  if (v3 && S >= 8) S &= ~7;   // whole rounds over the 8 XCDs (see the block-order note in the kernel)
+  // v4 (LDS-DMA ring, one workgroup per CU): saved bf16 inputs of plain stride-1 3x3 convs with at least two pixel
+  // tiles per workgroup.  PTI_WGRAD_V4=0 restores v3; PTI_WGRAD_V4_WGS sets the workgroup count it aims at (default 256).
+  static const int v4_env = getenv("PTI_WGRAD_V4") ? atoi(getenv("PTI_WGRAD_V4")) : 1;
+  static const int v4_wgs = getenv("PTI_WGRAD_V4_WGS") ? atoi(getenv("PTI_WGRAD_V4_WGS")) : 256;
+  const int tiles32 = (d->cout / 32) * (d->cin / 32);
+  bool v4 = v3 && v4_env && d->prologue == PTI_PRO_NONE && !d->in_f16 && d->mode == PTI_CONV_S1 &&
+            (long long)d->n * d->h * d->w * d->cin * 2 < (1ll << 31) && (long long)d->n * d->ho * d->wo * d->cout * 2 < (1ll << 31);
+  if (v4) {
+    int S4 = v4_wgs / tiles32;
+    if (S4 > a.ntiles / 2) S4 = a.ntiles / 2;
+    if (S4 > smax) S4 = (int)smax;
+    if (S4 < 1) S4 = 1;
+    if (S4 >= 8) S4 &= ~7;
+    S = S4;
+    a.ci_tiles = d->cin / 32;
+  }
+  else if (v3 && S >= 8) S &= ~7;   // whole rounds over the 8 XCDs (see the block-order note in the kernel)
   a.S = S;
   hipStream_t st = (hipStream_t)s;
-  if (v3 && cob == 2) hipLaunchKernelGGL((wgrad_mfma3_kernel<2, false>), dim3(tiles_cc * S), dim3(192), 0, st, a);
+  if (v4) hipLaunchKernelGGL(wgrad_mfma4_kernel, dim3(tiles32 * S), dim3(512), 0, st, a);
+  else if (v3 && cob == 2) hipLaunchKernelGGL((wgrad_mfma3_kernel<2, false>), dim3(tiles_cc * S), dim3(192), 0, st, a);
   else if (v3 && plain) hipLaunchKernelGGL((wgrad_mfma3_kernel<1, true>), dim3(tiles_cc * S), dim3(192), 0, st, a);
   else if (v3) hipLaunchKernelGGL((wgrad_mfma3_kernel<1, false>), dim3(tiles_cc * S), dim3(192), 0, st, a);
   else if (d->ksize == 1) launch_wt<1, 1>(a, co_t, ci_t, tiles_cc, st);
   else launch_wt<3, 2>(a, co_t, ci_t, tiles_cc, st);
   PTI_CHECK_LAUNCH("conv_wgrad_mfma");
-  *splits_out = S;
+  *splits_out = v4 ? (S | PTI_WGRAD_SLAB_V4) : S;   // the reduction must know the slab layout
   return PTI_OK;
 }
 
@@ -639,6 +961,13 @@ extern "C" int pti_conv_wgrad_reduce(const void* workspace, int splits, float* d
   if (!workspace || !dw || !d || splits < 1) PTI_FAIL(PTI_EINVAL, "conv_wgrad_reduce: bad arguments");
   const int kk = d->ksize * d->ksize;
   const long long total = (long long)kk * d->cout * d->cin + d->cout;
+  if (splits & PTI_WGRAD_SLAB_V4) {
+    if (kk != 9) PTI_FAIL(PTI_EINVAL, "conv_wgrad_reduce: block-ordered slabs are 3x3 only");
+    hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3((unsigned)((total / 4 + 15) / 16)), dim3(256), 0, (hipStream_t)s,
+                       (const float*)workspace, total, splits & ~PTI_WGRAD_SLAB_V4, dw, dbias, d->cout, d->cin, accumulate);
+    PTI_CHECK_LAUNCH("conv_wgrad_reduce");
+    return PTI_OK;
+  }
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total / 4 + 15) / 16)), dim3(256), 0, (hipStream_t)s,
                      (const float*)workspace, total, splits, dw, dbias, d->cout, d->cin, kk, accumulate);
   PTI_CHECK_LAUNCH("conv_wgrad_reduce");

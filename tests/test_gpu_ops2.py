@@ -15,6 +15,13 @@ WG_CASES = [
     # n, cin, cout, h, w, ks, mode, prologue
     (2, 32, 32, 16, 16, 3, "s1", 2),
     (3, 32, 32, 24, 40, 3, "s1", 0),     # many tiles, several splits, ragged
+    # plain bf16 inputs of stride-1 3x3 convs (the training step's saved activated inputs): the LDS-DMA ring kernel (v4)
+    (2, 64, 64, 16, 16, 3, "s1", 0),
+    (2, 128, 128, 16, 32, 3, "s1", 0),
+    (1, 128, 64, 13, 19, 3, "s1", 0),    # ragged edges on both axes: zero-page pieces
+    (1, 256, 256, 8, 16, 3, "s1", 0),    # 64 (co, ci) blocks, one pixel split
+    (5, 32, 64, 40, 24, 3, "s1", 0),     # more tiles per workgroup than ring slots, tiles past the end
+    (1, 32, 32, 8, 16, 3, "s1", 0),      # a single tile: falls back to one split
     (2, 64, 64, 16, 16, 3, "s1", 2),
     (2, 32, 64, 13, 19, 3, "s1", 2),
     (2, 128, 128, 16, 16, 3, "s1", 2),
