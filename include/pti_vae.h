@@ -162,6 +162,23 @@ int pti_conv_wgrad_mfma_partials(const void* x, const void* dy, const int64_t* i
 int pti_conv_wgrad_reduce(const void* workspace, int splits, float* dw, float* dbias,
                           int accumulate, const pti_conv_desc* d, pti_stream_t s);
 
+/* Batched form for the training step: up to PTI_WGRAD_BATCH_MAX independent weight-gradient problems of plain
+ * stride-1 3x3 convs on bf16 inputs WITHOUT prologue (x = the saved activated input) in one partial launch + one
+ * reduction launch.  A launch has ~11 us of fixed cost (dispatch, ring fill, cross-wave reduction, slab drain) against
+ * 10..45 us of streaming per layer, and the layers' weight gradients are independent of each other, so the engine
+ * collects them while backward walks the layers and flushes a batch at a time.  Deterministic like the single form.  */
+#define PTI_WGRAD_BATCH_MAX 16
+typedef struct pti_wgrad_job {
+  const void* x;    /* bf16 [n,h,w,cin] */
+  const void* dy;   /* bf16 [n,h,w,cout] */
+  float* dw;        /* fp32 [cout,cin,3,3] */
+  float* dbias;     /* fp32 [cout] or NULL */
+  int32_t n, h, w, cin, cout;
+  int32_t accumulate;   /* += instead of = */
+} pti_wgrad_job;
+int pti_conv_wgrad_mfma_batched(const pti_wgrad_job* jobs, int njobs, void* workspace, int64_t workspace_bytes,
+                                pti_stream_t s);
+
 /* ---- GroupNorm(+SiLU) backward, 2x2 sum pool ---------------------------------------------- */
 /* dx = d/dx of act(GroupNorm(x)) given da (+ dres added), dgamma/dbeta += ; sums: float [n][c][2] scratch
  * (written, need not be zeroed); partials: float scratch of n * pti_gn_bwd_blocks(n, hw, c) * c * 2 elements;

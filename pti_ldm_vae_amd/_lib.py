@@ -31,6 +31,16 @@ class ConvDesc(C.Structure):
     ]
 
 
+class WgradJob(C.Structure):
+    """``pti_wgrad_job`` of include/pti_vae.h."""
+
+    _fields_ = [("x", C.c_void_p), ("dy", C.c_void_p), ("dw", C.c_void_p), ("dbias", C.c_void_p),
+                ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32),
+                ("accumulate", C.c_int32)]
+
+
+WGRAD_BATCH_MAX = 16   # PTI_WGRAD_BATCH_MAX
+
 _P = C.c_void_p
 _I = C.c_int
 _I64 = C.c_int64
@@ -55,6 +65,7 @@ SIGNATURES = {
     "pti_conv_wgrad_workspace_bytes": (_I64, [_I, _I, _I, _I]),
     "pti_conv_wgrad_mfma": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I, C.POINTER(ConvDesc), _P]),
     "pti_conv_wgrad_mfma_partials": (_I, [_P, _P, _P, _P, _P, _P, _I64, C.POINTER(ConvDesc), C.POINTER(_I), _P]),
+    "pti_conv_wgrad_mfma_batched": (_I, [C.POINTER(WgradJob), _I, _P, _I64, _P]),
     "pti_conv_wgrad_reduce": (_I, [_P, _I, _P, _P, _I, C.POINTER(ConvDesc), _P]),
     "pti_gn_bwd_blocks": (_I, [_I, _I, _I]),
     "pti_gn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _P]),

@@ -16,7 +16,11 @@
 namespace {
 
 constexpr int TH = 8, TW = 16;
-constexpr int PTI_WGRAD_SLAB_V4 = 1 << 30;   // flag in the slab token of pti_conv_wgrad_mfma_partials: block-ordered slabs (v4)
+constexpr int PTI_WGRAD_SLAB_V4 = 1 << 30;
+#ifndef PTI_WGRAD_BATCH_MAX
+#define PTI_WGRAD_BATCH_MAX 16
+#endif
+//   // flag in the slab token of pti_conv_wgrad_mfma_partials: block-ordered slabs (v4)
 
 struct WgArgs {
   const bf16* x;
@@ -536,7 +540,26 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 constexpr int W4_STG = 20 * 1024, W4_DP = 3, W4_NSTAGE = 2 * (W4_DP + 1), W4_IMG = 9 * 32 * 32 * 4;   // DP = pairs of tiles ahead
 constexpr int W4_LDS = (W4_NSTAGE * W4_STG > 4 * W4_IMG + 1024) ? W4_NSTAGE * W4_STG : 4 * W4_IMG + 1024;
 
-__global__ __launch_bounds__(512, 1) void wgrad_mfma4_kernel(WgArgs a) {
+// Up to PTI_WGRAD_BATCH_MAX independent weight-gradient problems in ONE launch (+ one slab-reduction launch): a launch
+// of this kernel costs ~11 us of fixed time (dispatch, ring fill, cross-wave reduction, slab drain) next to 10..45 us of
+// streaming on the training step's layers, and the layers' weight gradients do not depend on each other.  Workgroups
+// first_wg[j] .. first_wg[j+1]-1 belong to job j (ranges padded to multiples of 8 so that `id & 7` still names the XCD).
+struct W4Batch {
+  WgArgs job[PTI_WGRAD_BATCH_MAX];
+  float* dw[PTI_WGRAD_BATCH_MAX];
+  float* dbias[PTI_WGRAD_BATCH_MAX];
+  int accumulate[PTI_WGRAD_BATCH_MAX];
+  int first_wg[PTI_WGRAD_BATCH_MAX + 1];
+  int first_rblk[PTI_WGRAD_BATCH_MAX + 1];   // blocks of the reduction launch
+  int njobs;
+};
+
+__global__ __launch_bounds__(512, 1) void wgrad_mfma4_kernel(W4Batch b) {
+  int jb = 0;
+  while (jb + 1 < b.njobs && (int)blockIdx.x >= b.first_wg[jb + 1]) ++jb;   // block-uniform
+  const WgArgs& a = b.job[jb];
+  const int wg_id = blockIdx.x - b.first_wg[jb];
+  if (wg_id >= a.ci_tiles * (a.Cout / 32) * a.S) return;                     // padding workgroup
   constexpr int HWp = TW + 2, NPX = 10 * HWp, PP = 64, XB = 12 * 1024, STG = W4_STG, DP = W4_DP, NPS = DP + 1;   // NPS pair slots
   static_assert(W4_LDS <= 160 * 1024 && 5 * (DP - 1) <= 63, "ring must fit the LDS and the vmcnt counter");
   typedef short v4s __attribute__((ext_vector_type(4)));
@@ -548,7 +571,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_mfma4_kernel(WgArgs a) {
   const int grp = w8 >> 2, w = w8 & 3;
   int split, cc;   // XCD-aware block order (see v3)
   {
-    const int id = blockIdx.x, tiles_cc = a.ci_tiles * (a.Cout / 32);
+    const int id = wg_id, tiles_cc = a.ci_tiles * (a.Cout / 32);
     if (a.S >= 8) {
       const int k = id >> 3;
       cc = k % tiles_cc;
@@ -763,13 +786,19 @@ __global__ __launch_bounds__(512, 1) void wgrad_mfma4_kernel(WgArgs a) {
 
 // Slab reduction of the v4 layout: slab s = [(co,ci) block cc][tap][ci][co quad ^ (ci & 7)][4 co] + Cout bias sums.
 // Same fixed-order scheme as wgrad_reduce_kernel (16 float4 columns x 16 slab groups per block).
-__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* __restrict__ slab, long long stride, int S,
-                                                            float* __restrict__ dw, float* __restrict__ dbias, int Cout,
-                                                            int Cin, int accumulate) {
+__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(W4Batch b) {
   __shared__ f32x4 red[16][16];
+  int jb = 0;
+  while (jb + 1 < b.njobs && (int)blockIdx.x >= b.first_rblk[jb + 1]) ++jb;   // block-uniform
+  const WgArgs& a = b.job[jb];
+  const float* __restrict__ slab = a.slab;
+  float* __restrict__ dw = b.dw[jb];
+  float* __restrict__ dbias = b.dbias[jb];
+  const int S = a.S, Cout = a.Cout, Cin = a.Cin, accumulate = b.accumulate[jb];
+  const long long stride = a.slab_stride;
   const long long total = (long long)9 * Cout * Cin;
   const int col = threadIdx.x & 15, sg = threadIdx.x >> 4;
-  const long long e = ((long long)blockIdx.x * 16 + col) * 4;
+  const long long e = ((long long)(blockIdx.x - b.first_rblk[jb]) * 16 + col) * 4;
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
   if (e < total + Cout) {
     int k = sg;
@@ -862,6 +891,62 @@ void launch_wt(const WgArgs& a, int co_t, int ci_t, int grid_y, hipStream_t st) 
 
 }  // namespace
 
+// ---- v4 batch planning (host) -------------------------------------------------------------------------------------
+static void w4_fill_job(WgArgs& a, const void* x, const void* dy, int n, int h, int w, int cin, int cout) {
+  a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.in_stats = nullptr; a.gamma = a.beta = nullptr; a.slab = nullptr;
+  a.N = n; a.H = h; a.W = w; a.Cin = cin; a.Ho = h; a.Wo = w; a.Cout = cout;
+  a.mode = PTI_CONV_S1; a.prologue = PTI_PRO_NONE; a.groups = 0; a.eps = 0.f; a.inv_cnt = 0.f; a.x_f16 = 0;
+  a.tiles_x = cdiv(w, TW); a.tiles_y = cdiv(h, TH); a.ntiles = n * a.tiles_x * a.tiles_y;
+  a.ci_tiles = cin / 32;
+  a.slab_stride = (long long)9 * cout * cin + cout;
+  a.S = 1;
+  static const int diag_env = getenv("PTI_WGRAD_V4_DIAG") ? atoi(getenv("PTI_WGRAD_V4_DIAG")) : 0;
+  a.diag = diag_env;
+}
+static bool w4_eligible(int n, int h, int w, int cin, int cout) {
+  return n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && cin % 32 == 0 && cout % 32 == 0 &&
+         (long long)n * h * w * cin * 2 < (1ll << 31) && (long long)n * h * w * cout * 2 < (1ll << 31);
+}
+// Pixel splits per job so that every workgroup of the launch streams about the same number of tiles and the launch has
+// about `wgs` workgroups (default 256 = one per CU); workgroup / reduction-block ranges; slab carving.
+// Returns the floats of workspace used, or -1 if it does not fit.
+static long long w4_plan(W4Batch& b, float* workspace, long long workspace_floats) {
+  static const int wgs_env = getenv("PTI_WGRAD_V4_WGS") ? atoi(getenv("PTI_WGRAD_V4_WGS")) : 256;
+  // cost of one workgroup-tile: 72 MFMAs (~0.3 us) or, for the narrow layers, its share of bytes nobody else on the
+  // chip fetches (the x tile is shared by Cout/32 workgroups, the dy tile by Cin/32) at the ~24 GB/s one CU pulls from
+  // HBM: 32->32 streams 19.7 KB per tile = ~2.7x the MFMA time (measured: 0.8 us vs 0.3 us per tile)
+  static const double cost_div = getenv("PTI_WGRAD_V4_COST") ? atof(getenv("PTI_WGRAD_V4_COST")) : 0.0;   // 0: plain tile count
+  auto tile_cost = [](const WgArgs& a) {
+    if (cost_div <= 0.0) return 1.0;
+    const double bytes = 11520.0 / (a.Cout / 32) + 8192.0 / (a.Cin / 32);
+    return bytes / cost_div > 1.0 ? bytes / cost_div : 1.0;
+  };
+  double work = 0;   // cost-weighted workgroup-tiles of the whole launch
+  for (int j = 0; j < b.njobs; ++j) work += tile_cost(b.job[j]) * b.job[j].ci_tiles * (b.job[j].Cout / 32) * b.job[j].ntiles;
+  const double per_wg = work / wgs_env > 2.0 ? work / wgs_env : 2.0;   // work per workgroup aimed at (at least one pair)
+  long long used = 0;
+  int wg = 0, rb = 0;
+  for (int j = 0; j < b.njobs; ++j) {
+    WgArgs& a = b.job[j];
+    int S = (int)(tile_cost(a) * a.ntiles / per_wg + 0.5);
+    if (S > a.ntiles / 2) S = a.ntiles / 2;
+    if (S < 1) S = 1;
+    if (S >= 8) S &= ~7;   // whole rounds over the 8 XCDs (block-order note in the kernel)
+    while (S > 1 && used + (long long)S * a.slab_stride > workspace_floats) S = S >= 16 ? (S - 8) : S - 1;
+    if (used + (long long)S * a.slab_stride > workspace_floats) return -1;
+    a.S = S;
+    a.slab = workspace + used;
+    used += (long long)S * a.slab_stride;
+    b.first_wg[j] = wg;
+    wg += (a.ci_tiles * (a.Cout / 32) * S + 7) & ~7;
+    b.first_rblk[j] = rb;
+    rb += (int)((a.slab_stride / 4 + 15) / 16);
+  }
+  b.first_wg[b.njobs] = wg;
+  b.first_rblk[b.njobs] = rb;
+  return used;
+}
+
 extern "C" int64_t pti_conv_wgrad_workspace_bytes(int cout, int cin, int ksize, int splits) {
   return (int64_t)splits * ((int64_t)ksize * ksize * cout * cin + cout) * 4;
 }
@@ -926,33 +1011,34 @@ extern "C" int pti_conv_wgrad_mfma_partials(const void* x, const void* dy, const
   if (S < 1) S = 1;
   if (S > smax) S = (int)smax;
   if (S < 1) PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma: workspace too small (%lld bytes per split needed)", a.slab_stride * 4);
-  // v4 (LDS-DMA ring, one workgroup per CU): saved bf16 inputs of plain stride-1 3x3 convs with at least two pixel
-  // tiles per workgroup.  PTI_WGRAD_V4=0 restores v3; PTI_WGRAD_V4_WGS sets the workgroup count it aims at (default 256).
+  // v4 (LDS-DMA ring, one workgroup per CU): saved bf16 inputs of plain stride-1 3x3 convs.  PTI_WGRAD_V4=0 restores
+  // v3; PTI_WGRAD_V4_WGS sets the workgroup count a launch aims at (default 256).
   static const int v4_env = getenv("PTI_WGRAD_V4") ? atoi(getenv("PTI_WGRAD_V4")) : 1;
-  static const int v4_wgs = getenv("PTI_WGRAD_V4_WGS") ? atoi(getenv("PTI_WGRAD_V4_WGS")) : 256;
-  const int tiles32 = (d->cout / 32) * (d->cin / 32);
-  bool v4 = v3 && v4_env && d->prologue == PTI_PRO_NONE && !d->in_f16 && d->mode == PTI_CONV_S1 &&
-            (long long)d->n * d->h * d->w * d->cin * 2 < (1ll << 31) && (long long)d->n * d->ho * d->wo * d->cout * 2 < (1ll << 31);
+  const bool v4 = v3 && v4_env && d->prologue == PTI_PRO_NONE && !d->in_f16 && d->mode == PTI_CONV_S1 &&
+                  w4_eligible(d->n, d->h, d->w, d->cin, d->cout);
   if (v4) {
-    int S4 = v4_wgs / tiles32;
-    if (S4 > a.ntiles / 2) S4 = a.ntiles / 2;
-    if (S4 > smax) S4 = (int)smax;
-    if (S4 < 1) S4 = 1;
-    if (S4 >= 8) S4 &= ~7;
-    S = S4;
-    a.ci_tiles = d->cin / 32;
+    W4Batch b;
+    b.njobs = 1;
+    w4_fill_job(b.job[0], x, dy, d->n, d->h, d->w, d->cin, d->cout);
+    b.dw[0] = b.dbias[0] = nullptr;
+    b.accumulate[0] = 0;
+    if (w4_plan(b, (float*)workspace, workspace_bytes / 4) < 0)
+      PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma: workspace too small (%lld bytes per split needed)", a.slab_stride * 4);
+    hipLaunchKernelGGL(wgrad_mfma4_kernel, dim3(b.first_wg[1]), dim3(512), 0, (hipStream_t)s, b);
+    PTI_CHECK_LAUNCH("conv_wgrad_mfma");
+    *splits_out = b.job[0].S | PTI_WGRAD_SLAB_V4;   // the reduction must know the slab layout
+    return PTI_OK;
   }
-  else if (v3 && S >= 8) S &= ~7;   // whole rounds over the 8 XCDs (see the block-order note in the kernel)
+  if (v3 && S >= 8) S &= ~7;   // whole rounds over the 8 XCDs (see the block-order note in the kernel)
   a.S = S;
   hipStream_t st = (hipStream_t)s;
-  if (v4) hipLaunchKernelGGL(wgrad_mfma4_kernel, dim3(tiles32 * S), dim3(512), 0, st, a);
-  else if (v3 && cob == 2) hipLaunchKernelGGL((wgrad_mfma3_kernel<2, false>), dim3(tiles_cc * S), dim3(192), 0, st, a);
+  if (v3 && cob == 2) hipLaunchKernelGGL((wgrad_mfma3_kernel<2, false>), dim3(tiles_cc * S), dim3(192), 0, st, a);
   else if (v3 && plain) hipLaunchKernelGGL((wgrad_mfma3_kernel<1, true>), dim3(tiles_cc * S), dim3(192), 0, st, a);
   else if (v3) hipLaunchKernelGGL((wgrad_mfma3_kernel<1, false>), dim3(tiles_cc * S), dim3(192), 0, st, a);
   else if (d->ksize == 1) launch_wt<1, 1>(a, co_t, ci_t, tiles_cc, st);
   else launch_wt<3, 2>(a, co_t, ci_t, tiles_cc, st);
   PTI_CHECK_LAUNCH("conv_wgrad_mfma");
-  *splits_out = v4 ? (S | PTI_WGRAD_SLAB_V4) : S;   // the reduction must know the slab layout
+  *splits_out = S;
   return PTI_OK;
 }
 
@@ -962,9 +1048,17 @@ extern "C" int pti_conv_wgrad_reduce(const void* workspace, int splits, float* d
   const int kk = d->ksize * d->ksize;
   const long long total = (long long)kk * d->cout * d->cin + d->cout;
   if (splits & PTI_WGRAD_SLAB_V4) {
-    if (kk != 9) PTI_FAIL(PTI_EINVAL, "conv_wgrad_reduce: block-ordered slabs are 3x3 only");
-    hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3((unsigned)((total / 4 + 15) / 16)), dim3(256), 0, (hipStream_t)s,
-                       (const float*)workspace, total, splits & ~PTI_WGRAD_SLAB_V4, dw, dbias, d->cout, d->cin, accumulate);
+    if (kk != 9 || !w4_eligible(d->n, d->h, d->w, d->cin, d->cout)) PTI_FAIL(PTI_EINVAL, "conv_wgrad_reduce: block-ordered slabs are 3x3 only");
+    W4Batch b;
+    b.njobs = 1;
+    w4_fill_job(b.job[0], nullptr, nullptr, d->n, d->h, d->w, d->cin, d->cout);
+    b.job[0].S = splits & ~PTI_WGRAD_SLAB_V4;
+    b.job[0].slab = (float*)workspace;
+    b.dw[0] = dw; b.dbias[0] = dbias; b.accumulate[0] = accumulate;
+    b.first_wg[0] = b.first_rblk[0] = 0;
+    b.first_wg[1] = 0;
+    b.first_rblk[1] = (int)((total / 4 + 15) / 16);
+    hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(b.first_rblk[1]), dim3(256), 0, (hipStream_t)s, b);
     PTI_CHECK_LAUNCH("conv_wgrad_reduce");
     return PTI_OK;
   }
@@ -981,4 +1075,27 @@ extern "C" int pti_conv_wgrad_mfma(const void* x, const void* dy, const int64_t*
   int splits = 0;
   if (int rc = pti_conv_wgrad_mfma_partials(x, dy, in_stats, gamma, beta, workspace, workspace_bytes, d, &splits, s)) return rc;
   return pti_conv_wgrad_reduce(workspace, splits, dw, dbias, accumulate, d, s);
+}
+
+extern "C" int pti_conv_wgrad_mfma_batched(const pti_wgrad_job* jobs, int njobs, void* workspace, int64_t workspace_bytes,
+                                           pti_stream_t s) {
+  if (!jobs || !workspace || njobs < 1 || njobs > PTI_WGRAD_BATCH_MAX)
+    PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma_batched: 1..%d jobs", PTI_WGRAD_BATCH_MAX);
+  W4Batch b;
+  b.njobs = njobs;
+  for (int j = 0; j < njobs; ++j) {
+    const pti_wgrad_job& q = jobs[j];
+    if (!q.x || !q.dy || !q.dw) PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma_batched: job %d has a null pointer", j);
+    if (!w4_eligible(q.n, q.h, q.w, q.cin, q.cout))
+      PTI_FAIL(PTI_EUNSUPPORTED, "conv_wgrad_mfma_batched: job %d: n=%d h=%d w=%d cin=%d cout=%d (channels must be multiples of 32, tensors < 2 GiB)",
+               j, q.n, q.h, q.w, q.cin, q.cout);
+    w4_fill_job(b.job[j], q.x, q.dy, q.n, q.h, q.w, q.cin, q.cout);
+    b.dw[j] = q.dw; b.dbias[j] = q.dbias; b.accumulate[j] = q.accumulate;
+  }
+  if (w4_plan(b, (float*)workspace, workspace_bytes / 4) < 0) PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma_batched: workspace too small");
+  hipLaunchKernelGGL(wgrad_mfma4_kernel, dim3(b.first_wg[njobs]), dim3(512), 0, (hipStream_t)s, b);
+  PTI_CHECK_LAUNCH("conv_wgrad_mfma_batched");
+  hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(b.first_rblk[njobs]), dim3(256), 0, (hipStream_t)s, b);
+  PTI_CHECK_LAUNCH("conv_wgrad_mfma_batched reduce");
+  return PTI_OK;
 }

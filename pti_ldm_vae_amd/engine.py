@@ -127,6 +127,9 @@ class _MfmaConv:
 
     def wgrad(self, x, dy, *, pro=PTI_PRO_NONE, norm=None, eng=None):
         dw, db = self.grads()
+        if eng.batch_wgrad and ops.wgrad_batch_eligible(x.t, dy, self.ksize, self.mode, pro):
+            eng.defer_wgrad(x.t, dy, dw, db)     # launched with other layers' weight gradients (Engine.flush_wgrad)
+            return
         g, b = (norm.weight.data, norm.bias.data) if norm is not None else (None, None)
         ws = eng.wgrad_stream
         if ws is None:
@@ -326,6 +329,14 @@ class Engine:
         self.wgrad_stream = torch.cuda.Stream(device=self.dev) if os.environ.get("PTI_WGRAD_STREAM", "1") == "1" else None
         self.workspace_side = torch.empty_like(self.workspace) if self.wgrad_stream is not None else None
         self._wgrad_pending = False
+        # weight gradients of the plain 3x3 convs are collected while backward walks the layers and launched a batch
+        # at a time (one launch has ~11 us of fixed cost against 10-45 us of streaming per layer, and the layers'
+        # weight gradients are independent): PTI_WGRAD_BATCH = jobs per launch (default 16 = the C-ABI's maximum; 1 = off).
+        # With a gradient exchange attached (data parallel) "gradients ready" notifications wait for the batch that
+        # holds their layers (see _ready / flush_wgrad).
+        self.wgrad_batch_max = max(1, min(ops.L.WGRAD_BATCH_MAX, int(os.environ.get("PTI_WGRAD_BATCH", "16"))))
+        self.batch_wgrad = self.wgrad_batch_max > 1
+        self._wgrad_jobs, self._ready_queue = [], []
         ops.L.lib()  # fail loudly now if the HIP extension is missing
         for c in net.channels:
             if c % 32:
@@ -458,8 +469,36 @@ class Engine:
             ops.wgrad_direct(wide, narrow, *args, workspace=self.workspace_side, **kw)
         self._wgrad_pending = True
 
+    def defer_wgrad(self, x, dy, dw, db):
+        self._wgrad_jobs.append((x, dy, dw, db))
+        if len(self._wgrad_jobs) >= self.wgrad_batch_max:
+            self.flush_wgrad()
+
+    def flush_wgrad(self):
+        """Launch the collected weight gradients (side stream if there is one), then hand the queued "gradients ready"
+        ranges to the exchange -- in their original order, behind that launch."""
+        jobs, self._wgrad_jobs = self._wgrad_jobs, []
+        ws = self.wgrad_stream
+        if jobs:
+            if ws is None:
+                ops.conv_wgrad_mfma_batched(jobs, workspace=self.workspace)
+            else:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                ws.wait_event(ev)
+                for x, dy, _, _ in jobs:
+                    x.record_stream(ws)
+                    dy.record_stream(ws)
+                with torch.cuda.stream(ws):
+                    ops.conv_wgrad_mfma_batched(jobs, workspace=self.workspace_side)
+                self._wgrad_pending = True
+        queue, self._ready_queue = self._ready_queue, []
+        for rng in queue:
+            self._emit_ready(rng)
+
     def join_wgrad(self):
         """Make the current stream wait for the side-stream weight gradients issued so far."""
+        self.flush_wgrad()
         if self.wgrad_stream is not None and self._wgrad_pending:
             ev = torch.cuda.Event()
             ev.record(self.wgrad_stream)
@@ -480,6 +519,17 @@ class Engine:
                     hi = o + (n + 3) // 4 * 4 if hi is None else max(hi, o + (n + 3) // 4 * 4)
             rng = self._range_cache[prefixes] = (lo, hi)
         if rng[0] is None:
+            return
+        if self._wgrad_jobs or self._ready_queue:   # some of this range's weight gradients may still be waiting in the batch
+            self._ready_queue.append(rng)
+            if len(self._ready_queue) >= 6:         # do not let the exchange fall far behind backward
+                self.flush_wgrad()
+            return
+        self._emit_ready(rng)
+
+    def _emit_ready(self, rng):
+        cb = self.grad_ready_cb
+        if cb is None:
             return
         ws = self.wgrad_stream
         if ws is None:

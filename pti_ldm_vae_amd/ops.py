@@ -327,6 +327,45 @@ def _wgrad_kernel_name(ksize, mode, cin, cout, ntiles, prologue=PTI_PRO_NONE, x_
             f"{str(prologue == PTI_PRO_NONE).lower()}>")
 
 
+def wgrad_batch_eligible(x, dy, ksize, mode, prologue):
+    """Whether pti_conv_wgrad_mfma_batched can take this weight gradient: plain stride-1 3x3, bf16 x without prologue."""
+    return (ksize == 3 and mode == PTI_CONV_S1 and prologue == PTI_PRO_NONE and x.dtype == BF16 and dy.dtype == BF16
+            and x.shape[3] % 32 == 0 and dy.shape[3] % 32 == 0 and x.numel() * 2 < (1 << 31) and dy.numel() * 2 < (1 << 31))
+
+
+def conv_wgrad_mfma_batched(jobs, workspace=None, accumulate=True):
+    """``jobs``: up to WGRAD_BATCH_MAX tuples (x [n,h,w,cin] bf16, dy [n,h,w,cout] bf16, dw fp32 [cout*cin*9], dbias fp32
+    [cout] | None) of plain stride-1 3x3 convs -> ONE partial launch + ONE reduction launch on the current stream."""
+    if not 1 <= len(jobs) <= L.WGRAD_BATCH_MAX:
+        raise ValueError(f"conv_wgrad_mfma_batched: 1..{L.WGRAD_BATCH_MAX} jobs, got {len(jobs)}")
+    arr = (L.WgradJob * len(jobs))()
+    flops = nbytes = 0.0
+    for i, (x, dy, dw, db) in enumerate(jobs):
+        _chk(x, BF16, "x", 4)
+        _chk(dy, BF16, "dy", 4)
+        _chk(dw, F32, "dw")
+        n, h, w, cin = x.shape
+        cout = dy.shape[3]
+        if tuple(dy.shape) != (n, h, w, cout) or dw.numel() != cout * cin * 9 or (db is not None and db.numel() != cout):
+            raise ValueError(f"conv_wgrad_mfma_batched: job {i}: shapes")
+        if db is not None:
+            _chk(db, F32, "dbias")
+        arr[i] = L.WgradJob(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), None if db is None else db.data_ptr(), n, h, w, cin,
+                            cout, int(accumulate))
+        flops += 2.0 * n * h * w * cout * cin * 9
+        nbytes += 2.0 * (x.numel() + dy.numel())
+    ws = workspace if workspace is not None else wgrad_workspace(jobs[0][0].device)
+    prof = KERNEL_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    L.check(L.lib().pti_conv_wgrad_mfma_batched(arr, len(jobs), _ptr(ws), ws.numel() * 4, _stream()),
+            "pti_conv_wgrad_mfma_batched")
+    if prof is not None:   # partial + reduction launches of the whole batch
+        e1.record()
+        prof.append(("wgrad_mfma4_kernel+wgrad_reduce4_kernel (batched)", flops, nbytes, e0, e1))
+
+
 def gn_bwd(x, da, dx, stats, gamma, beta, sums, dgamma, dbeta, *, groups, eps=1e-6, silu=True, dres=None):
     """dx <- backward of act(GroupNorm(x)); ``sums`` is an fp32 [n,c,2] scratch (written; no zeroing needed)."""
     _chk(x, ACT16, "x", 4)

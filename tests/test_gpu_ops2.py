@@ -215,3 +215,44 @@ def test_casts(dev):
     ops.cast_nhwc_bf16_to_nchw_f32(y, z)
     torch.cuda.synchronize()
     assert torch.equal(z.cpu(), x)
+
+
+def test_conv_wgrad_mfma_batched(dev):
+    """pti_conv_wgrad_mfma_batched: heterogeneous jobs (different channel counts, map sizes, ragged edges, batch sizes) in one
+    partial launch + one reduction launch; every job against autograd of F.conv2d; accumulate adds; a repeat is bitwise
+    identical (fixed summation order)."""
+    from pti_ldm_vae_amd import ops
+    torch.manual_seed(41)
+    shapes = [(2, 32, 32, 16, 16), (1, 64, 128, 13, 19), (3, 128, 64, 24, 16), (2, 128, 128, 8, 8), (1, 32, 64, 40, 24),
+              (2, 256, 256, 8, 16), (1, 64, 64, 8, 16)]
+    jobs, refs = [], []
+    for n, cin, cout, h, w in shapes:
+        x = _r(torch.randn(n, cin, h, w) * 1.2 + 0.1)
+        wt = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+        b = torch.zeros(cout, requires_grad=True)
+        y = F.conv2d(x, wt, b, padding=1)
+        dy = _r(torch.randn_like(y))
+        y.backward(dy)
+        dw = torch.full((cout * cin * 9,), float("nan"), device=dev)
+        db = torch.full((cout,), float("nan"), device=dev)
+        jobs.append((_nhwc(x).to(dev, torch.bfloat16), _nhwc(dy).to(dev, torch.bfloat16), dw, db))
+        refs.append((wt.grad, b.grad))
+    ops.conv_wgrad_mfma_batched(jobs, accumulate=False)
+    torch.cuda.synchronize()
+    first = [(j[2].clone(), j[3].clone()) for j in jobs]
+    for (n, cin, cout, h, w), (_, _, dw, db), (rw, rb) in zip(shapes, jobs, refs):
+        _report(f"batched wgrad [{cin}->{cout} {h}x{w} b{n}] dW", dw.view(cout, cin, 3, 3), rw, max_frac=2e-3, l2=2e-4)
+        _report("batched wgrad db", db, rb, max_frac=1e-4, l2=2e-5)
+    ops.conv_wgrad_mfma_batched(jobs, accumulate=True)
+    torch.cuda.synchronize()
+    for (_, _, dw, db), (rw, rb) in zip(jobs, refs):
+        _report("batched wgrad accumulate", dw.view(rw.shape), 2 * rw, max_frac=2e-3, l2=2e-4)
+    for j in jobs:
+        j[2].fill_(float("nan")); j[3].fill_(float("nan"))
+    ops.conv_wgrad_mfma_batched(jobs, accumulate=False)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, j[2]) and torch.equal(b, j[3]) for (a, b), j in zip(first, jobs))
+    with pytest.raises(ValueError):
+        ops.conv_wgrad_mfma_batched([])
+    with pytest.raises(ValueError):
+        ops.conv_wgrad_mfma_batched(jobs * 3)
