@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0   # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0       # HBM3E spec, same guide (~6.3 TB/s is what a streaming kernel reaches)
-PMC_TRAFFIC_FILE = "r01_pmc_traffic.json"   # tools/pmc_traffic.py output of the two --pmc passes
+PMC_TRAFFIC_FILE = "r02_pmc_traffic.json"   # tools/pmc_traffic.py output of the two --pmc passes of THIS command
 TRAIN_GFLOP_PER_IMG_A = 148.11   # BASELINE.md §3 (config A, 256x256, 1 channel; fwd 49.37 x 3)
 
 
@@ -72,66 +72,85 @@ def cpu_baseline(cfg_def, size, batch, steps):
         if i > 0:
             times.append(time.perf_counter() - t0)
     dt = sum(times) / len(times)
-    # the reference's own thread setting (torch.set_num_threads(4), train_vae.py:94), one timed step
+    # the reference's own thread setting (torch.set_num_threads(4), train_vae.py:94): 1 warm-up + 5 timed steps
     torch.set_num_threads(min(4, cores))
     t4 = []
-    for i in range(2):
+    for i in range(6):
         eps = torch.randn(batch, cfg_def["latent_channels"], lat, lat)
         t0 = time.perf_counter()
         opt.zero_grad(set_to_none=True)
         loss, *_ = train_step_losses(model, x, eps)
         loss.backward()
         opt.step()
-        t4.append(time.perf_counter() - t0)
+        if i > 0:
+            t4.append(time.perf_counter() - t0)
     torch.set_num_threads(cores)
     return {"value": round(batch / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
-            "value_at_reference_threads": round(batch / t4[-1], 4), "reference_threads": min(4, cores),
+            "value_at_reference_threads": round(batch * len(t4) / sum(t4), 4), "reference_threads": min(4, cores),
             "sample": f"oracle fp32 train step (fwd+L1+KL+bwd+Adam), config A {size}x{size}, batch {batch}, "
-                      f"1 warm-up + {steps} timed steps, torch threads={cores}; plus 1 warm-up + 1 timed step at the "
+                      f"1 warm-up + {steps} timed steps, torch threads={cores}; plus 1 warm-up + 5 timed steps at the "
                       f"reference's torch.set_num_threads(4)"}
 
 
+def _pmc():
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)))
+    except (OSError, ValueError):
+        return None
+
+
 def roofline_from_profile(rec, steps):
-    """Aggregate ops.KERNEL_PROFILE records (name, flops, bytes, start, end) of ``steps`` instrumented steps into the
-    ``roofline`` object: dominant kernel by time, bound chosen by its algorithmic intensity against the machine balance."""
-    roofline = None
-    if True:
-        agg = {}
-        for name, flops, nbytes, e0, e1 in rec:
-            a = agg.setdefault(name, [0.0, 0.0, 0.0, 0])
-            a[0] += e0.elapsed_time(e1) * 1e-3
+    """Aggregate ops.KERNEL_PROFILE records (kernel name as the HIP runtime reports it, algorithmic flops, bytes, start,
+    end event, shape) of ``steps`` instrumented steps into (roofline object of the dominant kernel by time, per-shape
+    table).  The bound follows the kernel's algorithmic intensity against the machine balance (2.5 PFLOP/s / 8 TB/s)."""
+    pmc = _pmc()
+    pk = pmc["kernels"] if pmc else {}
+    balance = PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+    agg, shp = {}, {}
+    for name, flops, nbytes, e0, e1, shape in rec:
+        dt = e0.elapsed_time(e1) * 1e-3
+        for table, key in ((agg, name), (shp, (shape[:7], name))):
+            a = table.setdefault(key, [0.0, 0.0, 0.0, 0])
+            a[0] += dt
             a[1] += flops
             a[2] += nbytes
             a[3] += 1
-        if agg:
-            name, (tsec, flops, nbytes, cnt) = max(agg.items(), key=lambda kv: kv[1][0])
-            # which roof bounds the dominant kernel: its algorithmic intensity against the machine balance
-            intensity = flops / nbytes
-            hbm_bound = intensity < PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
-            tfl, gbs = flops / tsec / 1e12, nbytes / tsec / 1e9
-            traffic = None   # HBM bytes per launch from the separate rocprofv3 --pmc passes committed under profiles/
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)))["kernels"].get(name)
-                if pmc:
-                    traffic = pmc["fetch_bytes"] + pmc["write_bytes"]
-            except (OSError, ValueError, KeyError):
-                pass
-            roofline = {"kernel": name, "bound": "hbm" if hbm_bound else "mfma",
-                        "achieved": round(gbs if hbm_bound else tfl, 2),
-                        "peak": PEAK_HBM_GBS if hbm_bound else PEAK_BF16_TFLOPS,
-                        "unit": "GB/s" if hbm_bound else "TFLOP/s",
-                        "frac": round(gbs / PEAK_HBM_GBS if hbm_bound else tfl / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                        "traffic_source": f"profiles/{PMC_TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, avg per launch)",
-                        "algorithmic_bytes_per_launch": round(nbytes / cnt),
-                        "algorithmic_gflop_per_launch": round(flops / cnt / 1e9, 3),
-                        "flop_per_byte": round(intensity, 1),
-                        "launches_per_step": cnt // steps, "avg_launch_us": round(tsec / cnt * 1e6, 2),
-                        "algorithmic_tflops": round(tfl, 1), "algorithmic_hbm_gbs": round(gbs, 1),
-                        "all_mfma_kernels": {k: {"ms_per_step": round(v[0] / steps * 1e3, 3),
-                                                 "tflops": round(v[1] / v[0] / 1e12, 1),
-                                                 "gbs": round(v[2] / v[0] / 1e9), "launches": v[3] // steps}
-                                             for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}}
-    return roofline
+    if not agg:
+        return None, []
+    name, (tsec, flops, nbytes, cnt) = max(agg.items(), key=lambda kv: kv[1][0])
+    intensity = flops / nbytes
+    hbm_bound = intensity < balance
+    tfl, gbs = flops / tsec / 1e12, nbytes / tsec / 1e9
+    traffic = (pk[name]["fetch_bytes"] + pk[name]["write_bytes"]) if name in pk else None
+    roofline = {"kernel": name, "kernel_name_source": "pti_last_kernel_name() = hipKernelNameRefByPtr of the launched function",
+                "bound": "hbm" if hbm_bound else "mfma",
+                "achieved": round(gbs if hbm_bound else tfl, 2),
+                "peak": PEAK_HBM_GBS if hbm_bound else PEAK_BF16_TFLOPS,
+                "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                "frac": round(gbs / PEAK_HBM_GBS if hbm_bound else tfl / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                "traffic_source": f"profiles/{PMC_TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, avg per launch)",
+                "algorithmic_bytes_per_launch": round(nbytes / cnt),
+                "algorithmic_gflop_per_launch": round(flops / cnt / 1e9, 3),
+                "flop_per_byte": round(intensity, 1),
+                "launches_per_step": round(cnt / steps, 2), "avg_launch_us": round(tsec / cnt * 1e6, 2),
+                "algorithmic_tflops": round(tfl, 1), "algorithmic_hbm_gbs": round(gbs, 1),
+                "all_mfma_kernels": {k: {"ms_per_step": round(v[0] / steps * 1e3, 3),
+                                         "tflops": round(v[1] / v[0] / 1e12, 1),
+                                         "gbs": round(v[2] / v[0] / 1e9), "launches": round(v[3] / steps, 2)}
+                                     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}}
+    table = []
+    for (shape, kname), (t, fl, nb, c) in sorted(shp.items(), key=lambda kv: -kv[1][0]):
+        kind, cin, cout, ho, wo, ks, mode = shape
+        row = {"op": kind, "cin": cin, "cout": cout, "out_hw": [ho, wo], "k": ks, "gather": mode, "kernel": kname,
+               "launches_per_step": round(c / steps, 2), "avg_us": round(t / c * 1e6, 1), "ms_per_step": round(t / steps * 1e3, 3),
+               "tflops": round(fl / t / 1e12, 1), "frac_mfma_peak": round(fl / t / 1e12 / PEAK_BF16_TFLOPS, 4),
+               "alg_gbs": round(nb / t / 1e9), "frac_hbm_peak": round(nb / t / 1e9 / PEAK_HBM_GBS, 4),
+               "alg_mb_per_launch": round(nb / c / 1e6, 1), "flop_per_byte": round(fl / nb, 1),
+               "bound": "hbm" if fl / nb < balance else "mfma"}
+        if kname in pk:   # counter bytes are per kernel SYMBOL (average over all its launches), not per shape
+            row["counter_mb_per_launch_kernel_avg"] = round((pk[kname]["fetch_bytes"] + pk[kname]["write_bytes"]) / 1e6, 1)
+        table.append(row)
+    return roofline, table
 
 
 def bench_regression(args, cfg, dev, world, rank, dist):
@@ -200,7 +219,7 @@ def bench_regression(args, cfg, dev, world, rank, dist):
     torch.cuda.synchronize()
     if rank == 0:
         rec, ops.KERNEL_PROFILE = ops.KERNEL_PROFILE, None
-        roofline = roofline_from_profile(rec, 2)
+        roofline, per_shape = roofline_from_profile(rec, 2)
         enc_gflop = 17.66 * (size / 256.0) ** 2 if tuple(cfg_def["channels"]) == (32, 64, 128, 128) else None
         value = args.batch * world * args.steps / dt
         line = {"metric": "vae_encoder_regression_images_per_sec_256x256_bf16", "value": round(value, 2), "unit": "images/s",
@@ -213,7 +232,7 @@ def bench_regression(args, cfg, dev, world, rank, dist):
                            "global_batch": args.batch * world, "parallelism": f"dp{world}", "final_loss": round(float(loss.item()), 5)},
                 "model_tflops_per_gpu": round(value / world * enc_gflop / 1e3, 1) if enc_gflop else None,
                 "frac_of_mfma_peak_end_to_end": round(value / world * enc_gflop / 1e3 / PEAK_BF16_TFLOPS, 4) if enc_gflop else None,
-                "roofline": roofline}
+                "roofline": roofline, "per_shape": per_shape}
         print(json.dumps(line), flush=True)
     if world > 1:
         d.destroy_process_group()
@@ -228,7 +247,7 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--config", default=os.path.join(ROOT, "config", "vae_dente_no_adv.json"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=16,
+    ap.add_argument("--cpu-steps", type=int, default=10,
                     help="timed oracle steps of the cpu_baseline leg (batch 4: ~10 s of CPU work on 16 cores)")
     args = ap.parse_args()
 
@@ -290,11 +309,28 @@ def main():
             log("first step done")
     sync_all()
     log(f"timing {args.steps} steps")
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    host = 0.0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
+        h0 = time.perf_counter()
         out = trainer.step(images, attributes=attrs)
+        host += time.perf_counter() - h0          # time the host spends enqueuing (incl. waiting on the 2-steps-in-flight cap)
+        marks[i + 1].record()
     sync_all()
     dt = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))   # ms, GPU-side step-to-step
+    pct = lambda q: per_step[min(len(per_step) - 1, int(q * len(per_step)))]
+    # pure host enqueue time of a step: a few steps issued with the steps-in-flight cap lifted and no sync in between
+    # (the host runs ahead of the GPU; in the timed region above `host` also contains the waits on that cap)
+    cap, trainer.max_steps_in_flight = trainer.max_steps_in_flight, 1 << 20
+    h0 = time.perf_counter()
+    for _ in range(4):
+        trainer.step(images, attributes=attrs)
+    host_only = (time.perf_counter() - h0) / 4
+    sync_all()
+    trainer.max_steps_in_flight = cap
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -303,7 +339,7 @@ def main():
     log(f"timed region {dt:.3f}s, loss {loss:.5f}; instrumented steps")
 
     # ---- instrumented steps: per-launch event timing of the MFMA conv + weight-gradient kernels (rank 0) ----
-    roofline = None
+    roofline, per_shape = None, []
     if rank == 0:
         ops.KERNEL_PROFILE = []
     # per-kernel durations are taken with the weight gradients back on the main stream: in the timed region they
@@ -317,7 +353,7 @@ def main():
     trainer.eng.wgrad_stream = side
     if rank == 0:
         rec, ops.KERNEL_PROFILE = ops.KERNEL_PROFILE, None
-        roofline = roofline_from_profile(rec, 2)
+        roofline, per_shape = roofline_from_profile(rec, 2)
     if world > 1:
         dist.barrier()
 
@@ -339,8 +375,16 @@ def main():
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss, 5)},
             "model_tflops_per_gpu": round(per_gpu * gflop_img / 1e3, 1) if gflop_img else None,
             "frac_of_mfma_peak_end_to_end": round(per_gpu * gflop_img / 1e3 / PEAK_BF16_TFLOPS, 4) if gflop_img else None,
-            "roofline": roofline,
+            "step_ms_median": round(pct(0.5), 3), "step_ms_p10": round(pct(0.1), 3), "step_ms_p90": round(pct(0.9), 3),
+            "host_enqueue_ms_per_step": round(host_only * 1e3, 3),
+            "host_in_step_call_ms_per_step": round(host / args.steps * 1e3, 3),
+            "roofline": roofline, "per_shape": per_shape,
         }
+        pmc = _pmc()
+        if pmc and "bytes_per_step" in pmc:   # HBM-side bytes of a whole step (all kernels) from the committed counter passes
+            line["end_to_end_hbm_bytes_per_step"] = pmc["bytes_per_step"]
+            line["end_to_end_hbm_frac"] = round(pmc["bytes_per_step"] / (dt / args.steps) / (PEAK_HBM_GBS * 1e9), 4)
+            line["end_to_end_hbm_source"] = f"profiles/{PMC_TRAFFIC_FILE}: sum over kernels of (2 x FETCH_SIZE + WRITE_SIZE) x launches per step"
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline (oracle) ...")
             line["cpu_baseline"] = cpu_baseline(cfg_def, args.size, 4, args.cpu_steps)

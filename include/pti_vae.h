@@ -80,6 +80,9 @@ typedef struct pti_conv_desc {
 
 int pti_abi_version(void);
 const char* pti_last_error_string(void);
+/* Symbol of the (last) kernel the calling thread's most recent pti_* call launched, demangled, as the HIP runtime and
+ * rocprofv3 name it; "" before the first launch.  Diagnostics: lets a caller pair its own timings with profiler rows. */
+const char* pti_last_kernel_name(void);
 
 /* ---- weights ------------------------------------------------------------------------- */
 /* Bytes of the MFMA-packed bf16 image of a [cout,cin,k,k] fp32 weight (0 if unsupported).  */

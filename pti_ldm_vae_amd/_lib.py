@@ -51,6 +51,7 @@ _F = C.c_float
 SIGNATURES = {
     "pti_abi_version": (_I, []),
     "pti_last_error_string": (C.c_char_p, []),
+    "pti_last_kernel_name": (C.c_char_p, []),
     "pti_conv_packed_bytes": (_I64, [_I, _I, _I, _I]),
     "pti_conv_pack_weights": (_I, [C.POINTER(_P), _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "pti_conv_pack_entry_bytes": (_I, []),

@@ -424,9 +424,9 @@ extern "C" int pti_attention_fwd(const void* qkv, void* o, float* lse2, int b, i
   const float c_log2 = 1.4426950408889634f / sqrtf((float)c);
   dim3 grid((l + TB - 1) / TB, b), blk(64 * NW);
   hipStream_t st = (hipStream_t)s;
-  if (c == 64) hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, blk, 0, st, (const bf16*)qkv, (bf16*)o, lse2, l, c_log2);
-  else if (c == 128) hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, blk, 0, st, (const bf16*)qkv, (bf16*)o, lse2, l, c_log2);
-  else hipLaunchKernelGGL(attn_fwd_kernel<256>, grid, blk, 0, st, (const bf16*)qkv, (bf16*)o, lse2, l, c_log2);
+  if (c == 64) PTI_LAUNCH(attn_fwd_kernel<64>, grid, blk, 0, st, (const bf16*)qkv, (bf16*)o, lse2, l, c_log2);
+  else if (c == 128) PTI_LAUNCH(attn_fwd_kernel<128>, grid, blk, 0, st, (const bf16*)qkv, (bf16*)o, lse2, l, c_log2);
+  else PTI_LAUNCH(attn_fwd_kernel<256>, grid, blk, 0, st, (const bf16*)qkv, (bf16*)o, lse2, l, c_log2);
   PTI_CHECK_LAUNCH("attention_fwd");
   return PTI_OK;
 }
@@ -440,19 +440,19 @@ extern "C" int pti_attention_bwd(const void* qkv, const void* o, const void* dou
   const long long rows = (long long)b * l;
   long long db = (rows + (256 / (c / 8)) - 1) / (256 / (c / 8));
   if (db > 4096) db = 4096;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)db), dim3(256), 0, st, (const bf16*)o, (const bf16*)dout, delta, rows, c);
+  PTI_LAUNCH(attn_delta_kernel, dim3((unsigned)db), dim3(256), 0, st, (const bf16*)o, (const bf16*)dout, delta, rows, c);
   PTI_CHECK_LAUNCH("attention_delta");
   dim3 grid((l + TB - 1) / TB, b), blk(64 * NW);
   const bf16* Q = (const bf16*)qkv; const bf16* DO = (const bf16*)dout; bf16* DQ = (bf16*)dqkv;
   if (c == 64) {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, grid, blk, 0, st, Q, DO, lse2, delta, DQ, l, c_log2, scale);
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64, 1>), grid, blk, 0, st, Q, DO, lse2, delta, DQ, l, c_log2, scale);
+    PTI_LAUNCH(attn_bwd_dq_kernel<64>, grid, blk, 0, st, Q, DO, lse2, delta, DQ, l, c_log2, scale);
+    PTI_LAUNCH((attn_bwd_dkdv_kernel<64, 1>), grid, blk, 0, st, Q, DO, lse2, delta, DQ, l, c_log2, scale);
   } else if (c == 128) {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, grid, blk, 0, st, Q, DO, lse2, delta, DQ, l, c_log2, scale);
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128, 1>), grid, blk, 0, st, Q, DO, lse2, delta, DQ, l, c_log2, scale);
+    PTI_LAUNCH(attn_bwd_dq_kernel<128>, grid, blk, 0, st, Q, DO, lse2, delta, DQ, l, c_log2, scale);
+    PTI_LAUNCH((attn_bwd_dkdv_kernel<128, 1>), grid, blk, 0, st, Q, DO, lse2, delta, DQ, l, c_log2, scale);
   } else {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<256>, grid, blk, 0, st, Q, DO, lse2, delta, DQ, l, c_log2, scale);
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<256, 2>), dim3((l + TB - 1) / TB, b, 2), blk, 0, st, Q, DO, lse2, delta, DQ, l, c_log2, scale);
+    PTI_LAUNCH(attn_bwd_dq_kernel<256>, grid, blk, 0, st, Q, DO, lse2, delta, DQ, l, c_log2, scale);
+    PTI_LAUNCH((attn_bwd_dkdv_kernel<256, 2>), dim3((l + TB - 1) / TB, b, 2), blk, 0, st, Q, DO, lse2, delta, DQ, l, c_log2, scale);
   }
   PTI_CHECK_LAUNCH("attention_bwd");
   return PTI_OK;

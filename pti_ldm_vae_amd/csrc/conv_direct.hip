@@ -490,7 +490,7 @@ extern "C" int pti_conv2d_direct(const void* x, const float* w, const float* bia
     if (d->out_f32) PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_direct: wide output must be 16-bit NHWC");
     a.wide_f16 = d->out_f16;
     dim3 grid((unsigned)((npix + 255) / 256), d->cout / 32);
-    hipLaunchKernelGGL(direct_fewcin_kernel, grid, dim3(256), 0, (hipStream_t)s, a);
+    PTI_LAUNCH(direct_fewcin_kernel, grid, dim3(256), 0, (hipStream_t)s, a);
   } else if (d->cout <= 16 && d->cin % 8 == 0 && d->cin >= 8 && d->cin <= 512 && !(d->cin & (d->cin - 1))) {
     if (d->in_f32) PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_direct: wide input must be 16-bit NHWC");
     a.wide_f16 = d->in_f16;
@@ -507,7 +507,7 @@ extern "C" int pti_conv2d_direct(const void* x, const float* w, const float* bia
       const size_t lds = pbytes + (a.w_lds ? wbytes : 0);
       long long blocks = (long long)d->n * tiles_x * tiles_y;
       if (blocks > 1024) blocks = 1024;
-      hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)s, a, tiles_x, tiles_y);
+      PTI_LAUNCH(kern, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)s, a, tiles_x, tiles_y);
     };
     if (d->cout == 1) launch(FoCfg<1>{}, direct_fewcout_kernel<1>);
     else if (d->cout <= 4) launch(FoCfg<4>{}, direct_fewcout_kernel<4>);
@@ -551,10 +551,10 @@ extern "C" int pti_wgrad_direct(const void* wide, const void* narrow, float* dw,
   while (blocks > 1 && blocks * cn * per * 4 > workspace_bytes) blocks /= 2;
   if (blocks * cn * per * 4 > workspace_bytes) PTI_FAIL(PTI_EINVAL, "wgrad_direct: workspace too small");
   a.part = (float*)workspace;
-  hipLaunchKernelGGL(wgrad_direct_kernel, dim3((unsigned)blocks, cn), dim3(256), 4 * 80 * (cw / 8) * sizeof(float),
+  PTI_LAUNCH(wgrad_direct_kernel, dim3((unsigned)blocks, cn), dim3(256), 4 * 80 * (cw / 8) * sizeof(float),
                      (hipStream_t)s, a);
   PTI_CHECK_LAUNCH("wgrad_direct");
-  hipLaunchKernelGGL(wgrad_direct_finalize_kernel, dim3((unsigned)((per + 255) / 256), cn), dim3(256), 0, (hipStream_t)s, a,
+  PTI_LAUNCH(wgrad_direct_finalize_kernel, dim3((unsigned)((per + 255) / 256), cn), dim3(256), 0, (hipStream_t)s, a,
                      (int)blocks);
   PTI_CHECK_LAUNCH("wgrad_direct");
   return PTI_OK;

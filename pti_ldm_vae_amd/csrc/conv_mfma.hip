@@ -910,18 +910,18 @@ int launch2_cfg(ConvArgs a, hipStream_t st) {
   constexpr int FPRO = PXF == 4 ? PTI_PRO_GN_SILU : -1;
   if constexpr (KS == 3) {   // the activated-input side output is a separate instantiation (3x3 only)
     if (a.act_out) {
-      if (fwd_silu) hipLaunchKernelGGL((conv_mfma2_kernel<KS, CK, CT, PXF, true, 1, FPRO>), grid, dim3(256), 0, st, a);
-      else hipLaunchKernelGGL((conv_mfma2_kernel<KS, CK, CT, PXF, true, 0, -1>), grid, dim3(256), 0, st, a);
+      if (fwd_silu) PTI_LAUNCH((conv_mfma2_kernel<KS, CK, CT, PXF, true, 1, FPRO>), grid, dim3(256), 0, st, a);
+      else PTI_LAUNCH((conv_mfma2_kernel<KS, CK, CT, PXF, true, 0, -1>), grid, dim3(256), 0, st, a);
       return 0;
     }
   } else if (a.act_out) {
     return 1;
   }
-  if (fwd_silu) hipLaunchKernelGGL((conv_mfma2_kernel<KS, CK, CT, PXF, false, 1, FPRO>), grid, dim3(256), 0, st, a);
-  else if (fwd_plain) hipLaunchKernelGGL((conv_mfma2_kernel<KS, CK, CT, PXF, false, 1, PTI_PRO_NONE>), grid, dim3(256), 0, st, a);
-  else if (dgrad) hipLaunchKernelGGL((conv_mfma2_kernel<KS, CK, CT, PXF, false, 2, PTI_PRO_NONE>), grid, dim3(256), 0, st, a);
-  else if (dgrad_gn) hipLaunchKernelGGL((conv_mfma2_kernel<KS, CK, CT, PXF, false, 3, PTI_PRO_NONE>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((conv_mfma2_kernel<KS, CK, CT, PXF, false, 0, -1>), grid, dim3(256), 0, st, a);
+  if (fwd_silu) PTI_LAUNCH((conv_mfma2_kernel<KS, CK, CT, PXF, false, 1, FPRO>), grid, dim3(256), 0, st, a);
+  else if (fwd_plain) PTI_LAUNCH((conv_mfma2_kernel<KS, CK, CT, PXF, false, 1, PTI_PRO_NONE>), grid, dim3(256), 0, st, a);
+  else if (dgrad) PTI_LAUNCH((conv_mfma2_kernel<KS, CK, CT, PXF, false, 2, PTI_PRO_NONE>), grid, dim3(256), 0, st, a);
+  else if (dgrad_gn) PTI_LAUNCH((conv_mfma2_kernel<KS, CK, CT, PXF, false, 3, PTI_PRO_NONE>), grid, dim3(256), 0, st, a);
+  else PTI_LAUNCH((conv_mfma2_kernel<KS, CK, CT, PXF, false, 0, -1>), grid, dim3(256), 0, st, a);
   return 0;
 }
 template <int KS>
@@ -1004,8 +1004,8 @@ __global__ void pack_weights_batched_kernel(const PackArgs* __restrict__ table, 
 template <int KS, int S, int CK, int COUT_TILE>
 int launch_cfg(const ConvArgs& a, hipStream_t st) {
   dim3 grid(a.N * a.tiles_x * a.tiles_y, a.Cout / COUT_TILE);
-  if (a.w_f16) hipLaunchKernelGGL((conv_mfma_kernel<KS, S, CK, COUT_TILE, true>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((conv_mfma_kernel<KS, S, CK, COUT_TILE, false>), grid, dim3(256), 0, st, a);
+  if (a.w_f16) PTI_LAUNCH((conv_mfma_kernel<KS, S, CK, COUT_TILE, true>), grid, dim3(256), 0, st, a);
+  else PTI_LAUNCH((conv_mfma_kernel<KS, S, CK, COUT_TILE, false>), grid, dim3(256), 0, st, a);
   return 0;
 }
 
@@ -1056,7 +1056,7 @@ extern "C" int pti_conv_pack_weights(const float* const* w, int nsrc, void* pack
   p.ck = (mode == PTI_CONV_S2PAD) ? pick_ck(p.cin_l, true) : pick_ck2(p.cin_l, p.cout_tile);
   p.total = (long long)p.cout_l * p.cin_l * ksize * ksize;
   const int blocks = (int)((p.total + 2047) / 2048);
-  hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, p);
+  PTI_LAUNCH(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, p);
   PTI_CHECK_LAUNCH("pack_weights");
   return PTI_OK;
 }
@@ -1094,7 +1094,7 @@ extern "C" int pti_conv_pack_table_fill(void* host_entry, const float* w, void* 
 extern "C" int pti_conv_pack_weights_batched(const void* table_dev, const int* blk_first_dev, int n, int total_blocks,
                                              pti_stream_t s) {
   if (!table_dev || !blk_first_dev || n <= 0 || total_blocks <= 0) PTI_FAIL(PTI_EINVAL, "pack_weights_batched: bad args");
-  hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)s,
+  PTI_LAUNCH(pack_weights_batched_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)s,
                      (const PackArgs*)table_dev, blk_first_dev, n);
   PTI_CHECK_LAUNCH("pack_weights_batched");
   return PTI_OK;

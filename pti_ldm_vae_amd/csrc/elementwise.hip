@@ -454,7 +454,7 @@ extern "C" int pti_latent_head_fwd(const float* h, const float* eps, const float
   if (!h || !wm || !bm || !wl || !bl || !wp || !bp || !mu || !sigma || !zq) PTI_FAIL(PTI_EINVAL, "latent_head_fwd: null pointer");
   if (l <= 0 || l > MAXL || b <= 0 || hw <= 0) PTI_FAIL(PTI_EUNSUPPORTED, "latent_head_fwd: latent channels %d (max %d)", l, MAXL);
   LatArgs a{h, eps, wm, bm, wl, bl, wp, bp, mu, sigma, logvar, zq, b, hw, l};
-  hipLaunchKernelGGL(latent_fwd_kernel, dim3(nblocks((long long)b * hw)), dim3(256), 0, (hipStream_t)s, a);
+  PTI_LAUNCH(latent_fwd_kernel, dim3(nblocks((long long)b * hw)), dim3(256), 0, (hipStream_t)s, a);
   PTI_CHECK_LAUNCH("latent_head_fwd");
   return PTI_OK;
 }
@@ -462,7 +462,7 @@ extern "C" int pti_latent_head_fwd(const float* h, const float* eps, const float
 extern "C" int pti_post_quant(const float* z_nchw, const float* wp, const float* bp, float* zq_nhwc, int b, int hw,
                               int l, pti_stream_t s) {
   if (!z_nchw || !wp || !bp || !zq_nhwc || l <= 0 || l > MAXL) PTI_FAIL(PTI_EINVAL, "post_quant: bad args");
-  hipLaunchKernelGGL(post_quant_kernel, dim3(nblocks((long long)b * hw)), dim3(256), 0, (hipStream_t)s, z_nchw, wp, bp,
+  PTI_LAUNCH(post_quant_kernel, dim3(nblocks((long long)b * hw)), dim3(256), 0, (hipStream_t)s, z_nchw, wp, bp,
                      zq_nhwc, b, hw, l);
   PTI_CHECK_LAUNCH("post_quant");
   return PTI_OK;
@@ -474,14 +474,14 @@ extern "C" int pti_post_quant_bwd(const float* dzq_nhwc, const float* z_nchw, co
   const unsigned nb = nblocks((long long)b * hw, PTI_POST_QUANT_BWD_MAX_BLOCKS);
   const int ll = l * l + l;
   if (l == 4)
-    hipLaunchKernelGGL(post_quant_bwd_kernel<4>, dim3(nb), dim3(256), 4 * ll * sizeof(float), (hipStream_t)s, dzq_nhwc,
+    PTI_LAUNCH(post_quant_bwd_kernel<4>, dim3(nb), dim3(256), 4 * ll * sizeof(float), (hipStream_t)s, dzq_nhwc,
                        z_nchw, wp, dz_nchw, workspace, b, hw, l);
   else   // other latent widths fold per-element partials with LDS float atomics inside a workgroup
-    hipLaunchKernelGGL(post_quant_bwd_kernel<0>, dim3(nb), dim3(256), ll * sizeof(float), (hipStream_t)s, dzq_nhwc, z_nchw,
+    PTI_LAUNCH(post_quant_bwd_kernel<0>, dim3(nb), dim3(256), ll * sizeof(float), (hipStream_t)s, dzq_nhwc, z_nchw,
                        wp, dz_nchw, workspace, b, hw, l);
   PTI_CHECK_LAUNCH("post_quant_bwd");
   FinSegs sg{{gwp, gbp}, {l * l, l}, 2};
-  hipLaunchKernelGGL(block_partials_finalize_kernel, dim3(ll), dim3(64), 0, (hipStream_t)s, workspace, (int)nb, ll, sg);
+  PTI_LAUNCH(block_partials_finalize_kernel, dim3(ll), dim3(64), 0, (hipStream_t)s, workspace, (int)nb, ll, sg);
   PTI_CHECK_LAUNCH("post_quant_bwd_finalize");
   return PTI_OK;
 }
@@ -501,17 +501,17 @@ extern "C" int pti_latent_head_bwd(const float* h, const float* eps, const float
   {   // ~4 elements per thread: the 60 wave reductions at the end are amortised
     nb = ((long long)b * hw + 1023) / 1024;
     nb = nb < 1 ? 1 : (nb > PTI_LATENT_BWD_MAX_BLOCKS ? PTI_LATENT_BWD_MAX_BLOCKS : nb);
-    hipLaunchKernelGGL(latent_bwd_kernel<4>, dim3((unsigned)nb), dim3(256), 4 * 3 * ll * sizeof(float), (hipStream_t)s, a);
+    PTI_LAUNCH(latent_bwd_kernel<4>, dim3((unsigned)nb), dim3(256), 4 * 3 * ll * sizeof(float), (hipStream_t)s, a);
   }
   else {
     // other latent widths: the per-element partials go through LDS float atomics inside a block (rounding order
     // may vary run to run there); the cross-block stage is the same fixed-order one
     nb = nblocks((long long)b * hw, 256);
-    hipLaunchKernelGGL(latent_bwd_kernel<0>, dim3((unsigned)nb), dim3(256), 3 * ll * sizeof(float), (hipStream_t)s, a);
+    PTI_LAUNCH(latent_bwd_kernel<0>, dim3((unsigned)nb), dim3(256), 3 * ll * sizeof(float), (hipStream_t)s, a);
   }
   PTI_CHECK_LAUNCH("latent_head_bwd");
   FinSegs sg{{gwm, gbm, gwl, gbl, gwp, gbp}, {l * l, l, l * l, l, l * l, l}, 6};
-  hipLaunchKernelGGL(block_partials_finalize_kernel, dim3(3 * ll), dim3(64), 0, (hipStream_t)s, workspace, (int)nb, 3 * ll, sg);
+  PTI_LAUNCH(block_partials_finalize_kernel, dim3(3 * ll), dim3(64), 0, (hipStream_t)s, workspace, (int)nb, 3 * ll, sg);
   PTI_CHECK_LAUNCH("latent_head_bwd_finalize");
   return PTI_OK;
 }
@@ -522,12 +522,12 @@ extern "C" int pti_vae_loss(const float* recon, const float* images, int64_t npi
   if (!recon || !images || !mu || !third || !out2 || !workspace || npix <= 0 || nlat <= 0 || batch <= 0)
     PTI_FAIL(PTI_EINVAL, "vae_loss: bad args");
   const unsigned nb = nblocks(npix, PTI_VAE_LOSS_MAX_BLOCKS);
-  hipLaunchKernelGGL(vae_loss_kernel, dim3(nb), dim3(256), 0, (hipStream_t)s, recon, images,
+  PTI_LAUNCH(vae_loss_kernel, dim3(nb), dim3(256), 0, (hipStream_t)s, recon, images,
                      (long long)npix, mu, third, (long long)nlat, workspace, d_recon, d_mu, d_third, l2, third_mode, kl_weight,
                      1.0f / (float)npix, 1.0f / (float)batch);
   PTI_CHECK_LAUNCH("vae_loss");
   FinSegs sg{{out2}, {2}, 1};
-  hipLaunchKernelGGL(block_partials_finalize_kernel, dim3(2), dim3(64), 0, (hipStream_t)s, workspace, (int)nb, 2, sg);
+  PTI_LAUNCH(block_partials_finalize_kernel, dim3(2), dim3(64), 0, (hipStream_t)s, workspace, (int)nb, 2, sg);
   PTI_CHECK_LAUNCH("vae_loss_finalize");
   return PTI_OK;
 }
@@ -539,7 +539,7 @@ extern "C" int pti_ar_vae_loss(const float* mu_nchw, int b, int l, int hw, const
   if (b <= 0 || l <= 0 || hw <= 0 || na <= 0) PTI_FAIL(PTI_EINVAL, "ar_vae_loss: bad sizes");
   if (b > AR_MAXB) PTI_FAIL(PTI_EUNSUPPORTED, "ar_vae_loss: local batch %d above %d", b, AR_MAXB);
   ArArgs a{mu_nchw, attrs, channels, deltas, pair_mask, per_attr, counts, d_mu, b, l, hw, na, gamma};
-  hipLaunchKernelGGL(ar_vae_kernel, dim3(l), dim3(256), 0, (hipStream_t)s, a);
+  PTI_LAUNCH(ar_vae_kernel, dim3(l), dim3(256), 0, (hipStream_t)s, a);
   PTI_CHECK_LAUNCH("ar_vae_loss");
   return PTI_OK;
 }
@@ -550,7 +550,7 @@ extern "C" int pti_adam_step(float* p, const float* g, float* m, float* v, int64
   // bias corrections in double, as torch.optim.Adam computes them (fp32 powf left ~1e-5 relative error at small steps)
   const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
   const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
-  hipLaunchKernelGGL(adam_kernel, dim3(nblocks(n, 2048)), dim3(256), 0, (hipStream_t)s, p, g, m, v, (long long)n, lr, beta1,
+  PTI_LAUNCH(adam_kernel, dim3(nblocks(n, 2048)), dim3(256), 0, (hipStream_t)s, p, g, m, v, (long long)n, lr, beta1,
                      beta2, eps, bc1, bc2s, grad_scale);
   PTI_CHECK_LAUNCH("adam_step");
   return PTI_OK;
@@ -558,13 +558,13 @@ extern "C" int pti_adam_step(float* p, const float* g, float* m, float* v, int64
 
 extern "C" int pti_cast_nchw_f32_to_nhwc_bf16(const float* x, void* y, int n, int c, int hw, pti_stream_t s) {
   if (!x || !y) PTI_FAIL(PTI_EINVAL, "cast: null");
-  hipLaunchKernelGGL(cast_nchw_f32_to_nhwc_bf16, dim3(nblocks((long long)n * c * hw)), dim3(256), 0, (hipStream_t)s, x, (bf16*)y, n, c, hw);
+  PTI_LAUNCH(cast_nchw_f32_to_nhwc_bf16, dim3(nblocks((long long)n * c * hw)), dim3(256), 0, (hipStream_t)s, x, (bf16*)y, n, c, hw);
   PTI_CHECK_LAUNCH("cast_nchw_f32_to_nhwc_bf16");
   return PTI_OK;
 }
 extern "C" int pti_cast_nhwc_bf16_to_nchw_f32(const void* x, float* y, int n, int c, int hw, pti_stream_t s) {
   if (!x || !y) PTI_FAIL(PTI_EINVAL, "cast: null");
-  hipLaunchKernelGGL(cast_nhwc_bf16_to_nchw_f32, dim3(nblocks((long long)n * c * hw)), dim3(256), 0, (hipStream_t)s, (const bf16*)x, y, n, c, hw);
+  PTI_LAUNCH(cast_nhwc_bf16_to_nchw_f32, dim3(nblocks((long long)n * c * hw)), dim3(256), 0, (hipStream_t)s, (const bf16*)x, y, n, c, hw);
   PTI_CHECK_LAUNCH("cast_nhwc_bf16_to_nchw_f32");
   return PTI_OK;
 }

@@ -99,7 +99,7 @@ extern "C" int pti_gn_stats(const void* x, int64_t* stats, int n, int hw, int c,
   if (ppb < 16 * ppi) ppb = 16 * ppi;
   ppb = cdiv(ppb, 4 * ppi) * 4 * ppi;
   bps = cdiv(hw, ppb);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(bps, n), dim3(256), 2 * groups * sizeof(stat_t), (hipStream_t)s,
+  PTI_LAUNCH(gn_stats_kernel, dim3(bps, n), dim3(256), 2 * groups * sizeof(stat_t), (hipStream_t)s,
                      (const bf16*)x, (stat_t*)stats, hw, c, groups, ppb, x_f16);
   PTI_CHECK_LAUNCH("gn_stats");
   return PTI_OK;
@@ -388,12 +388,12 @@ extern "C" int pti_gn_bwd(const void* x, const void* da, const void* dres, void*
   const int bps = gn_bwd_grid(n, hw, c, &ppb);
   a.ppb = ppb;
   a.part = partials;
-  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(bps, n), dim3(256), 8 * c * sizeof(float), (hipStream_t)s, a);
+  PTI_LAUNCH(gn_bwd_reduce_kernel, dim3(bps, n), dim3(256), 8 * c * sizeof(float), (hipStream_t)s, a);
   PTI_CHECK_LAUNCH("gn_bwd_reduce");
-  hipLaunchKernelGGL(gn_sums_finalize_kernel, dim3(cdiv(2 * c, 64), n), dim3(1024), 0, (hipStream_t)s, partials, sums,
+  PTI_LAUNCH(gn_sums_finalize_kernel, dim3(cdiv(2 * c, 64), n), dim3(1024), 0, (hipStream_t)s, partials, sums,
                      bps, 2 * c);
   PTI_CHECK_LAUNCH("gn_sums_finalize");
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(bps, n), dim3(256), 0, (hipStream_t)s, a);
+  PTI_LAUNCH(gn_bwd_apply_kernel, dim3(bps, n), dim3(256), 0, (hipStream_t)s, a);
   PTI_CHECK_LAUNCH("gn_bwd_apply");
   return PTI_OK;
 }
@@ -417,14 +417,14 @@ extern "C" int pti_gn_bwd_apply(const void* x, const void* dy, const void* dres,
   ppb = cdiv(ppb, ppi) * ppi;
   bps = cdiv(hw, ppb);
   a.ppb = ppb;
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(bps, n), dim3(256), 0, (hipStream_t)s, a);
+  PTI_LAUNCH(gn_bwd_apply_kernel, dim3(bps, n), dim3(256), 0, (hipStream_t)s, a);
   PTI_CHECK_LAUNCH("gn_bwd_apply");
   return PTI_OK;
 }
 
 extern "C" int pti_gn_sums_finalize(const float* partials, float* sums, int n, int tiles, int row_len, pti_stream_t s) {
   if (!partials || !sums || n <= 0 || tiles <= 0 || row_len <= 0) PTI_FAIL(PTI_EINVAL, "gn_sums_finalize: bad args");
-  hipLaunchKernelGGL(gn_sums_finalize_kernel, dim3(cdiv(row_len, 64), n), dim3(1024), 0, (hipStream_t)s, partials, sums,
+  PTI_LAUNCH(gn_sums_finalize_kernel, dim3(cdiv(row_len, 64), n), dim3(1024), 0, (hipStream_t)s, partials, sums,
                      tiles, row_len);
   PTI_CHECK_LAUNCH("gn_sums_finalize");
   return PTI_OK;
@@ -435,7 +435,7 @@ extern "C" int pti_pool2x2_sum(const void* x, void* y, int n, int h, int w, int 
   const long long total = (long long)n * h * w * (c / 8);
   long long blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(pool2x2_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, (const bf16*)x, (bf16*)y, n, h, w, c);
+  PTI_LAUNCH(pool2x2_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, (const bf16*)x, (bf16*)y, n, h, w, c);
   PTI_CHECK_LAUNCH("pool2x2_sum");
   return PTI_OK;
 }

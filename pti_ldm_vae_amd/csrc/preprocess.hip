@@ -89,9 +89,9 @@ extern "C" int pti_preprocess_batch(const float* src, const int64_t* offsets, co
   if (bx < 1) bx = 1;
   hipStream_t st = (hipStream_t)s;
   if (hipMemsetAsync(stats, 0, sizeof(double) * 3 * b, st) != hipSuccess) PTI_FAIL(PTI_ELAUNCH, "preprocess_batch: memset failed");
-  hipLaunchKernelGGL(pre_resize_kernel, dim3(bx, b), dim3(256), 0, st, a);
+  PTI_LAUNCH(pre_resize_kernel, dim3(bx, b), dim3(256), 0, st, a);
   PTI_CHECK_LAUNCH("preprocess_resize");
-  hipLaunchKernelGGL(pre_normalize_kernel, dim3(bx, b), dim3(256), 0, st, a);
+  PTI_LAUNCH(pre_normalize_kernel, dim3(bx, b), dim3(256), 0, st, a);
   PTI_CHECK_LAUNCH("preprocess_normalize");
   return PTI_OK;
 }

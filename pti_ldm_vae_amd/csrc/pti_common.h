@@ -24,6 +24,15 @@ void pti_set_error(const char* fmt, ...);
     pti_set_error(__VA_ARGS__);  \
     return (code);               \
   } while (0)
+// Every launch of this library goes through PTI_LAUNCH: it remembers the host-side function pointer of the kernel it
+// launched (per thread), so that pti_last_kernel_name() can ask the HIP runtime for the symbol that actually ran -- the
+// bench pairs its live timings with rocprofv3 records by that name instead of re-deriving the template arguments.
+extern thread_local const void* pti_last_kernel;
+#define PTI_LAUNCH(kernel, grid, block, shmem, stream, ...)                     \
+  do {                                                                           \
+    pti_last_kernel = reinterpret_cast<const void*>(kernel);                     \
+    hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);         \
+  } while (0)
 #define PTI_CHECK_LAUNCH(name)                                             \
   do {                                                                     \
     hipError_t e__ = hipGetLastError();                                    \

@@ -519,9 +519,9 @@ void wgrad_mfma3_kernel(WgArgs a) {   // COB 1: 3 waves/SIMD (<= 168 VGPR+AGPR),
 //     28 transposing LDS reads per wave and tile, two waves per SIMD on all four SIMDs (v3's three kernel-column waves
 //     left one SIMD without MFMA work); the eight partial blocks are summed through LDS once, at the end, in a fixed
 //     order;
-//   * ONE workgroup per CU (the ring is the latency hiding) => S = 256 / (co,ci blocks) pixel splits instead of
-//     1024..1280 workgroups: 256 x 37 KB = 9.4 MB of partial slabs per launch instead of 38..47 MB (which exceeded the
-//     17 MB of x + dy of the 128-channel 32^2 layers more than twice, written AND re-read);
+//   * ONE resident workgroup per CU (the ring is the latency hiding); batched over up to 16 layers per launch (W4Batch)
+//     the partial slabs are ~1024 x 37 KB = 38 MB per LAUNCH of 16 layers instead of 38..47 MB per LAYER (which
+//     exceeded the 17 MB of x + dy of the 128-channel 32^2 layers more than twice, written AND re-read);
 //   * out-of-image halo pixels / ragged tile edges / tiles past the end read a 16-byte zero page, so every wave issues
 //     exactly 5 DMA instructions per iteration and the vmcnt arithmetic is uniform; interior tiles (no edge in reach)
 //     skip the per-piece range checks;
@@ -542,26 +542,45 @@ constexpr int W4_LDS = (W4_NSTAGE * W4_STG > 4 * W4_IMG + 1024) ? W4_NSTAGE * W4
 
 // Up to PTI_WGRAD_BATCH_MAX independent weight-gradient problems in ONE launch (+ one slab-reduction launch): a launch
 // of this kernel costs ~11 us of fixed time (dispatch, ring fill, cross-wave reduction, slab drain) next to 10..45 us of
-// streaming on the training step's layers, and the layers' weight gradients do not depend on each other.  Workgroups
-// first_wg[j] .. first_wg[j+1]-1 belong to job j (ranges padded to multiples of 8 so that `id & 7` still names the XCD).
+// streaming on the training step's layers, and the layers' weight gradients do not depend on each other.
+struct W4Job {
+  const bf16* x; const bf16* dy; float* slab;
+  long long slab_stride;
+  int N, H, W, Cin, Cout, tiles_x, tiles_y, ntiles, S;
+};
+// Workgroup placement.  The (co, ci) blocks of one pixel split of one job stream the SAME x / dy tiles, so they must
+// share an XCD (one L2 per XCD; workgroup ids are dealt round-robin over the 8 XCDs: id & 7 names the XCD -- for speed
+// only, a different deal would only cost bandwidth).  A "group" = (job, split) = tiles32 workgroups.  The host deals
+// the groups of the whole batch over the eight XCDs (biggest first, onto the shortest list) and the kernel finds its
+// (job, split, block) from id & 7, id >> 3 and the group list of that XCD.  Measured without it on the batched launch
+// (S = 1..2 per job: consecutive ids = different blocks of one split, spread over all XCDs): 2.1x the algorithmic
+// bytes fetched.
+constexpr int W4_MAXGRP = 32;   // groups per XCD (=> at most 256 groups per launch)
 struct W4Batch {
-  WgArgs job[PTI_WGRAD_BATCH_MAX];
+  W4Job job[PTI_WGRAD_BATCH_MAX];
   float* dw[PTI_WGRAD_BATCH_MAX];
   float* dbias[PTI_WGRAD_BATCH_MAX];
   int accumulate[PTI_WGRAD_BATCH_MAX];
-  int first_wg[PTI_WGRAD_BATCH_MAX + 1];
   int first_rblk[PTI_WGRAD_BATCH_MAX + 1];   // blocks of the reduction launch
-  int njobs;
+  unsigned grp[8][W4_MAXGRP];                 // job | split << 8
+  unsigned short grp_start[8][W4_MAXGRP + 1]; // first position (id >> 3) of each group in its XCD's list
+  int ngrp[8];
+  int njobs, diag, nwg;
 };
 
 __global__ __launch_bounds__(512, 1) void wgrad_mfma4_kernel(W4Batch b) {
-  int jb = 0;
-  while (jb + 1 < b.njobs && (int)blockIdx.x >= b.first_wg[jb + 1]) ++jb;   // block-uniform
-  const WgArgs& a = b.job[jb];
-  const int wg_id = blockIdx.x - b.first_wg[jb];
-  if (wg_id >= a.ci_tiles * (a.Cout / 32) * a.S) return;                     // padding workgroup
   constexpr int HWp = TW + 2, NPX = 10 * HWp, PP = 64, XB = 12 * 1024, STG = W4_STG, DP = W4_DP, NPS = DP + 1;   // NPS pair slots
   static_assert(W4_LDS <= 160 * 1024 && 5 * (DP - 1) <= 63, "ring must fit the LDS and the vmcnt counter");
+  // ---- which (job, pixel split, (co,ci) block) is this workgroup? (block-uniform scalar code) ----
+  const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
+  const int ng = b.ngrp[xcd];
+  if (ng == 0 || pos >= b.grp_start[xcd][ng]) return;                        // padding workgroup of a shorter list
+  int gi = 0;
+  while (gi + 1 < ng && pos >= b.grp_start[xcd][gi + 1]) ++gi;
+  const unsigned gword = b.grp[xcd][gi];
+  const int jb = gword & 255, split = gword >> 8, cc = pos - b.grp_start[xcd][gi];
+  const W4Job& a = b.job[jb];
+  const int ci_tiles = a.Cin / 32;
   typedef short v4s __attribute__((ext_vector_type(4)));
   typedef short v8s __attribute__((ext_vector_type(8)));
   __shared__ __attribute__((aligned(16))) unsigned char smem[W4_LDS];
@@ -569,19 +588,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_mfma4_kernel(W4Batch b) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = w8 >> 2, w = w8 & 3;
-  int split, cc;   // XCD-aware block order (see v3)
-  {
-    const int id = wg_id, tiles_cc = a.ci_tiles * (a.Cout / 32);
-    if (a.S >= 8) {
-      const int k = id >> 3;
-      cc = k % tiles_cc;
-      split = (k / tiles_cc) * 8 + (id & 7);
-    } else {
-      cc = id / a.S;
-      split = id % a.S;
-    }
-  }
-  const int cot = cc / a.ci_tiles, cit = cc % a.ci_tiles;
+  const int cot = cc / ci_tiles, cit = cc % ci_tiles;
   const int co0 = cot * 32, ci0 = cit * 32;
   const bool do_bias = (cit == 0);   // block-uniform
 
@@ -600,7 +607,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_mfma4_kernel(W4Batch b) {
     const int i = (w + 4 * k) * 64 + lane, p = i >> 2;
     dty[k] = p >> 4;
     dtx[k] = p & 15;
-    drel[k] = (dty[k] * a.Wo + dtx[k]) * a.Cout * 2 + (co0 + (i & 3) * 8) * 2;
+    drel[k] = (dty[k] * a.W + dtx[k]) * a.Cout * 2 + (co0 + (i & 3) * 8) * 2;
   }
   const unsigned char* xb = reinterpret_cast<const unsigned char*>(a.x);
   const unsigned char* db = reinterpret_cast<const unsigned char*>(a.dy);
@@ -618,12 +625,12 @@ __global__ __launch_bounds__(512, 1) void wgrad_mfma4_kernel(W4Batch b) {
     const int n = t / a.tiles_y;
     tp.oy0 = ty_ * 8; tp.ox0 = tx_ * TW;
     tp.xt = xb + ((size_t)(n * a.H + tp.oy0) * a.W + tp.ox0) * a.Cin * 2;
-    tp.dt = db + ((size_t)(n * a.Ho + tp.oy0) * a.Wo + tp.ox0) * a.Cout * 2;
+    tp.dt = db + ((size_t)(n * a.H + tp.oy0) * a.W + tp.ox0) * a.Cout * 2;
     tp.interior = tp.oy0 >= 1 && tp.ox0 >= 1 && tp.oy0 + 9 <= a.H && tp.ox0 + 17 <= a.W;
     return tp;
   };
   auto issue_slot = [&](const TilePos& tp, int stage, int k) {   // k is a compile-time constant at every call site
-    if (a.diag & 1) return;                                   // tuning aid: no tile loads
+    if (b.diag & 1) return;                                   // tuning aid: no tile loads
     const unsigned sbase = lds0 + stage * STG + w * 1024;
     if (k < 3) {
       bool ok = tp.live && xhy[k] < 16;
@@ -635,7 +642,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_mfma4_kernel(W4Batch b) {
     } else {
       const int kk = k - 3;
       bool ok = tp.live;
-      if (!tp.interior) ok = ok && tp.oy0 + dty[kk] < a.Ho && tp.ox0 + dtx[kk] < a.Wo;
+      if (!tp.interior) ok = ok && tp.oy0 + dty[kk] < a.H && tp.ox0 + dtx[kk] < a.W;
       glds16(ok ? tp.dt + drel[kk] : zero, sbase + XB + kk * 4096);
     }
   };
@@ -713,7 +720,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_mfma4_kernel(W4Batch b) {
     wait_vmcnt<5 * (DP - 1)>();           // this wave's 5 pieces of pair `it` have landed (younger pairs may fly)
     __builtin_amdgcn_s_barrier();         // ... everyone's have, and everyone is done reading the slot refilled below
     // (the second tile of an odd last pair is a tile past the end: all zeros, it adds nothing)
-    if (a.diag & 2) {                     // tuning aid: loads only
+    if (b.diag & 2) {                     // tuning aid: loads only
 #pragma unroll
       for (int k = 0; k < 5; ++k) issue_slot(ft, 2 * fs + grp, k);
     } else {
@@ -759,8 +766,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_mfma4_kernel(W4Batch b) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) bred[w8 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel] = accb[r];
   }
-  if (a.diag & 8) return;
-  if (!(a.diag & 4)) {
+  if (b.diag & 8) return;
+  if (!(b.diag & 4)) {
     if (w8 >= 4) dump(red + (w8 - 4) * 9216);
     __syncthreads();
     if (w8 < 4) gather(red + w8 * 9216);
@@ -770,10 +777,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_mfma4_kernel(W4Batch b) {
     if (w8 < 2) gather(red + w8 * 9216);
     __syncthreads();
   }
-  if (w8 < 2 && !(a.diag & 32)) dump(red + w8 * 9216);
+  if (w8 < 2 && !(b.diag & 32)) dump(red + w8 * 9216);
   __syncthreads();
   float* slab = a.slab + (size_t)split * a.slab_stride + (size_t)cc * 9216;
-  if (!(a.diag & 16))
+  if (!(b.diag & 16))
   for (int i4 = tid; i4 < 2304; i4 += 512)
     *(f32x4*)(slab + i4 * 4) = *(const f32x4*)(red + i4 * 4) + *(const f32x4*)(red + 9216 + i4 * 4);
   if (do_bias && tid < 32) {
@@ -790,7 +797,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(W4Batch b) {
   __shared__ f32x4 red[16][16];
   int jb = 0;
   while (jb + 1 < b.njobs && (int)blockIdx.x >= b.first_rblk[jb + 1]) ++jb;   // block-uniform
-  const WgArgs& a = b.job[jb];
+  const W4Job& a = b.job[jb];
   const float* __restrict__ slab = a.slab;
   float* __restrict__ dw = b.dw[jb];
   float* __restrict__ dbias = b.dbias[jb];
@@ -877,9 +884,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 template <int KS, int S_, int CO_T, int CI_T>
 void launch_w(const WgArgs& a, int grid_y, hipStream_t st) {
   if (a.prologue == PTI_PRO_NONE)
-    hipLaunchKernelGGL((wgrad_mfma_kernel<KS, S_, CO_T, CI_T, true>), dim3(grid_y, a.S), dim3(256), 0, st, a);
+    PTI_LAUNCH((wgrad_mfma_kernel<KS, S_, CO_T, CI_T, true>), dim3(grid_y, a.S), dim3(256), 0, st, a);
   else
-    hipLaunchKernelGGL((wgrad_mfma_kernel<KS, S_, CO_T, CI_T, false>), dim3(grid_y, a.S), dim3(256), 0, st, a);
+    PTI_LAUNCH((wgrad_mfma_kernel<KS, S_, CO_T, CI_T, false>), dim3(grid_y, a.S), dim3(256), 0, st, a);
 }
 template <int KS, int S_>
 void launch_wt(const WgArgs& a, int co_t, int ci_t, int grid_y, hipStream_t st) {
@@ -892,59 +899,82 @@ void launch_wt(const WgArgs& a, int co_t, int ci_t, int grid_y, hipStream_t st) 
 }  // namespace
 
 // ---- v4 batch planning (host) -------------------------------------------------------------------------------------
-static void w4_fill_job(WgArgs& a, const void* x, const void* dy, int n, int h, int w, int cin, int cout) {
-  a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.in_stats = nullptr; a.gamma = a.beta = nullptr; a.slab = nullptr;
-  a.N = n; a.H = h; a.W = w; a.Cin = cin; a.Ho = h; a.Wo = w; a.Cout = cout;
-  a.mode = PTI_CONV_S1; a.prologue = PTI_PRO_NONE; a.groups = 0; a.eps = 0.f; a.inv_cnt = 0.f; a.x_f16 = 0;
+static void w4_fill_job(W4Job& a, const void* x, const void* dy, int n, int h, int w, int cin, int cout) {
+  a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.slab = nullptr;
+  a.N = n; a.H = h; a.W = w; a.Cin = cin; a.Cout = cout;
   a.tiles_x = cdiv(w, TW); a.tiles_y = cdiv(h, TH); a.ntiles = n * a.tiles_x * a.tiles_y;
-  a.ci_tiles = cin / 32;
   a.slab_stride = (long long)9 * cout * cin + cout;
   a.S = 1;
-  static const int diag_env = getenv("PTI_WGRAD_V4_DIAG") ? atoi(getenv("PTI_WGRAD_V4_DIAG")) : 0;
-  a.diag = diag_env;
 }
 static bool w4_eligible(int n, int h, int w, int cin, int cout) {
   return n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && cin % 32 == 0 && cout % 32 == 0 &&
          (long long)n * h * w * cin * 2 < (1ll << 31) && (long long)n * h * w * cout * 2 < (1ll << 31);
 }
 // Pixel splits per job so that every workgroup of the launch streams about the same number of tiles and the launch has
-// about `wgs` workgroups (default 256 = one per CU); workgroup / reduction-block ranges; slab carving.
+// about `wgs` workgroups; slab carving; reduction-block ranges; the XCD group lists.  One workgroup is resident per
+// CU (it owns the whole LDS); ~1024 workgroups = four rounds measured best inside the training step, where the launch
+// shares the chip with the data-gradient chain on the other stream (same-box A/B: 256 13.45, 512 13.07, 1024 12.90,
+// 2048 12.73..12.87 ms per step); the 256-group cap of the XCD lists bounds it from above.
 // Returns the floats of workspace used, or -1 if it does not fit.
 static long long w4_plan(W4Batch& b, float* workspace, long long workspace_floats) {
-  static const int wgs_env = getenv("PTI_WGRAD_V4_WGS") ? atoi(getenv("PTI_WGRAD_V4_WGS")) : 256;
-  // cost of one workgroup-tile: 72 MFMAs (~0.3 us) or, for the narrow layers, its share of bytes nobody else on the
-  // chip fetches (the x tile is shared by Cout/32 workgroups, the dy tile by Cin/32) at the ~24 GB/s one CU pulls from
-  // HBM: 32->32 streams 19.7 KB per tile = ~2.7x the MFMA time (measured: 0.8 us vs 0.3 us per tile)
-  static const double cost_div = getenv("PTI_WGRAD_V4_COST") ? atof(getenv("PTI_WGRAD_V4_COST")) : 0.0;   // 0: plain tile count
-  auto tile_cost = [](const WgArgs& a) {
-    if (cost_div <= 0.0) return 1.0;
-    const double bytes = 11520.0 / (a.Cout / 32) + 8192.0 / (a.Cin / 32);
-    return bytes / cost_div > 1.0 ? bytes / cost_div : 1.0;
-  };
-  double work = 0;   // cost-weighted workgroup-tiles of the whole launch
-  for (int j = 0; j < b.njobs; ++j) work += tile_cost(b.job[j]) * b.job[j].ci_tiles * (b.job[j].Cout / 32) * b.job[j].ntiles;
-  const double per_wg = work / wgs_env > 2.0 ? work / wgs_env : 2.0;   // work per workgroup aimed at (at least one pair)
-  long long used = 0;
-  int wg = 0, rb = 0;
-  for (int j = 0; j < b.njobs; ++j) {
-    WgArgs& a = b.job[j];
-    int S = (int)(tile_cost(a) * a.ntiles / per_wg + 0.5);
-    if (S > a.ntiles / 2) S = a.ntiles / 2;
-    if (S < 1) S = 1;
-    if (S >= 8) S &= ~7;   // whole rounds over the 8 XCDs (block-order note in the kernel)
-    while (S > 1 && used + (long long)S * a.slab_stride > workspace_floats) S = S >= 16 ? (S - 8) : S - 1;
-    if (used + (long long)S * a.slab_stride > workspace_floats) return -1;
-    a.S = S;
-    a.slab = workspace + used;
-    used += (long long)S * a.slab_stride;
-    b.first_wg[j] = wg;
-    wg += (a.ci_tiles * (a.Cout / 32) * S + 7) & ~7;
-    b.first_rblk[j] = rb;
-    rb += (int)((a.slab_stride / 4 + 15) / 16);
+  static const int wgs_env = getenv("PTI_WGRAD_V4_WGS") ? atoi(getenv("PTI_WGRAD_V4_WGS")) : 1024;
+  static const int diag_env = getenv("PTI_WGRAD_V4_DIAG") ? atoi(getenv("PTI_WGRAD_V4_DIAG")) : 0;
+  b.diag = diag_env;
+  auto tiles32 = [](const W4Job& a) { return (a.Cin / 32) * (a.Cout / 32); };
+  double work = 0;   // workgroup-tiles of the whole launch
+  for (int j = 0; j < b.njobs; ++j) work += (double)tiles32(b.job[j]) * b.job[j].ntiles;
+  double per_wg = work / wgs_env > 2.0 ? work / wgs_env : 2.0;   // tiles per workgroup aimed at (at least one pair)
+  for (int attempt = 0;; ++attempt) {
+    long long used = 0;
+    int rb = 0, groups = 0;
+    bool fits = true;
+    for (int j = 0; j < b.njobs; ++j) {
+      W4Job& a = b.job[j];
+      int S = (int)((double)a.ntiles / per_wg + 0.5);
+      if (S > a.ntiles / 2) S = a.ntiles / 2;
+      if (S > 255) S = 255;
+      if (S < 1) S = 1;
+      if (used + (long long)S * a.slab_stride > workspace_floats) fits = false;
+      a.S = S;
+      a.slab = workspace + used;
+      used += (long long)S * a.slab_stride;
+      groups += S;
+      b.first_rblk[j] = rb;
+      rb += (int)((a.slab_stride / 4 + 15) / 16);
+    }
+    b.first_rblk[b.njobs] = rb;
+    if (fits && groups <= 8 * W4_MAXGRP) {
+      // deal the groups over the XCDs: biggest first onto the currently shortest list
+      int len[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int x = 0; x < 8; ++x) { b.ngrp[x] = 0; b.grp_start[x][0] = 0; }
+      int order[PTI_WGRAD_BATCH_MAX];
+      for (int j = 0; j < b.njobs; ++j) order[j] = j;
+      for (int i = 0; i < b.njobs; ++i)
+        for (int j = i + 1; j < b.njobs; ++j)
+          if (tiles32(b.job[order[j]]) > tiles32(b.job[order[i]])) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
+      bool ok = true;
+      for (int i = 0; i < b.njobs && ok; ++i) {
+        const int j = order[i];
+        for (int sp = 0; sp < b.job[j].S; ++sp) {
+          int best = 0;
+          for (int x = 1; x < 8; ++x)
+            if (len[x] < len[best]) best = x;
+          if (b.ngrp[best] >= W4_MAXGRP || len[best] + tiles32(b.job[j]) > 65535) { ok = false; break; }
+          b.grp[best][b.ngrp[best]] = (unsigned)j | ((unsigned)sp << 8);
+          len[best] += tiles32(b.job[j]);
+          b.grp_start[best][++b.ngrp[best]] = (unsigned short)len[best];
+        }
+      }
+      if (ok) {
+        int mx = 0;
+        for (int x = 0; x < 8; ++x) mx = len[x] > mx ? len[x] : mx;
+        b.nwg = 8 * mx;
+        return used;
+      }
+    }
+    if (attempt > 40) return -1;
+    per_wg *= 1.25;   // fewer, longer splits
   }
-  b.first_wg[b.njobs] = wg;
-  b.first_rblk[b.njobs] = rb;
-  return used;
 }
 
 extern "C" int64_t pti_conv_wgrad_workspace_bytes(int cout, int cin, int ksize, int splits) {
@@ -1024,7 +1054,7 @@ extern "C" int pti_conv_wgrad_mfma_partials(const void* x, const void* dy, const
     b.accumulate[0] = 0;
     if (w4_plan(b, (float*)workspace, workspace_bytes / 4) < 0)
       PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma: workspace too small (%lld bytes per split needed)", a.slab_stride * 4);
-    hipLaunchKernelGGL(wgrad_mfma4_kernel, dim3(b.first_wg[1]), dim3(512), 0, (hipStream_t)s, b);
+    PTI_LAUNCH(wgrad_mfma4_kernel, dim3(b.nwg), dim3(512), 0, (hipStream_t)s, b);
     PTI_CHECK_LAUNCH("conv_wgrad_mfma");
     *splits_out = b.job[0].S | PTI_WGRAD_SLAB_V4;   // the reduction must know the slab layout
     return PTI_OK;
@@ -1032,9 +1062,9 @@ extern "C" int pti_conv_wgrad_mfma_partials(const void* x, const void* dy, const
   if (v3 && S >= 8) S &= ~7;   // whole rounds over the 8 XCDs (see the block-order note in the kernel)
   a.S = S;
   hipStream_t st = (hipStream_t)s;
-  if (v3 && cob == 2) hipLaunchKernelGGL((wgrad_mfma3_kernel<2, false>), dim3(tiles_cc * S), dim3(192), 0, st, a);
-  else if (v3 && plain) hipLaunchKernelGGL((wgrad_mfma3_kernel<1, true>), dim3(tiles_cc * S), dim3(192), 0, st, a);
-  else if (v3) hipLaunchKernelGGL((wgrad_mfma3_kernel<1, false>), dim3(tiles_cc * S), dim3(192), 0, st, a);
+  if (v3 && cob == 2) PTI_LAUNCH((wgrad_mfma3_kernel<2, false>), dim3(tiles_cc * S), dim3(192), 0, st, a);
+  else if (v3 && plain) PTI_LAUNCH((wgrad_mfma3_kernel<1, true>), dim3(tiles_cc * S), dim3(192), 0, st, a);
+  else if (v3) PTI_LAUNCH((wgrad_mfma3_kernel<1, false>), dim3(tiles_cc * S), dim3(192), 0, st, a);
   else if (d->ksize == 1) launch_wt<1, 1>(a, co_t, ci_t, tiles_cc, st);
   else launch_wt<3, 2>(a, co_t, ci_t, tiles_cc, st);
   PTI_CHECK_LAUNCH("conv_wgrad_mfma");
@@ -1055,14 +1085,15 @@ extern "C" int pti_conv_wgrad_reduce(const void* workspace, int splits, float* d
     b.job[0].S = splits & ~PTI_WGRAD_SLAB_V4;
     b.job[0].slab = (float*)workspace;
     b.dw[0] = dw; b.dbias[0] = dbias; b.accumulate[0] = accumulate;
-    b.first_wg[0] = b.first_rblk[0] = 0;
-    b.first_wg[1] = 0;
+    b.diag = 0; b.nwg = 0;
+    for (int x = 0; x < 8; ++x) b.ngrp[x] = 0;
+    b.first_rblk[0] = 0;
     b.first_rblk[1] = (int)((total / 4 + 15) / 16);
-    hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(b.first_rblk[1]), dim3(256), 0, (hipStream_t)s, b);
+    PTI_LAUNCH(wgrad_reduce4_kernel, dim3(b.first_rblk[1]), dim3(256), 0, (hipStream_t)s, b);
     PTI_CHECK_LAUNCH("conv_wgrad_reduce");
     return PTI_OK;
   }
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total / 4 + 15) / 16)), dim3(256), 0, (hipStream_t)s,
+  PTI_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((total / 4 + 15) / 16)), dim3(256), 0, (hipStream_t)s,
                      (const float*)workspace, total, splits, dw, dbias, d->cout, d->cin, kk, accumulate);
   PTI_CHECK_LAUNCH("conv_wgrad_reduce");
   return PTI_OK;
@@ -1093,9 +1124,10 @@ extern "C" int pti_conv_wgrad_mfma_batched(const pti_wgrad_job* jobs, int njobs,
     b.dw[j] = q.dw; b.dbias[j] = q.dbias; b.accumulate[j] = q.accumulate;
   }
   if (w4_plan(b, (float*)workspace, workspace_bytes / 4) < 0) PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma_batched: workspace too small");
-  hipLaunchKernelGGL(wgrad_mfma4_kernel, dim3(b.first_wg[njobs]), dim3(512), 0, (hipStream_t)s, b);
+  PTI_LAUNCH(wgrad_mfma4_kernel, dim3(b.nwg), dim3(512), 0, (hipStream_t)s, b);
   PTI_CHECK_LAUNCH("conv_wgrad_mfma_batched");
-  hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(b.first_rblk[njobs]), dim3(256), 0, (hipStream_t)s, b);
+  PTI_LAUNCH(wgrad_reduce4_kernel, dim3(b.first_rblk[njobs]), dim3(256), 0, (hipStream_t)s, b);
   PTI_CHECK_LAUNCH("conv_wgrad_mfma_batched reduce");
+  pti_last_kernel = reinterpret_cast<const void*>(wgrad_mfma4_kernel);   // pti_last_kernel_name(): the call's main kernel
   return PTI_OK;
 }

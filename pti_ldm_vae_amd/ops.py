@@ -151,53 +151,38 @@ def conv_mfma(x, w_packed, bias, y, *, cout, ksize=3, mode=PTI_CONV_S1, prologue
                 "pti_conv2d_mfma")
     if prof is not None:
         e1.record()
-        name = _conv_kernel_name(ksize, mode, cin, cout, act_out is not None, in_f16=x.dtype == F16, out_f16=y.dtype == F16,
-                                 res=residual is not None, res_f16=residual is not None and residual.dtype == F16,
-                                 prologue=prologue, pool2=pool2, stats=out_stats is not None)
         # algorithmic work; the zero-insert data gradient only has 1/4 useful taps per output pixel
         flops = 2.0 * n * ho * wo * cout * cin * ksize * ksize * (0.25 if mode == PTI_CONV_ZINS else 1.0)
-        # algorithmic bytes: read the input once (bf16), write the output once (+ residual read)
+        # algorithmic bytes: read the input once (16-bit), write the output once (+ residual read, + side output)
         nbytes = 2.0 * (x.numel() * (2 if act_out is not None else 1) + y.numel() * (2 if residual is not None else 1))   # (pooled y counted as stored)
-        prof.append((name, flops, nbytes, e0, e1))
+        kind = "conv fwd" if x.dtype == F16 or prologue != PTI_PRO_NONE else "conv dgrad"
+        prof.append((last_kernel_name(), flops, nbytes, e0, e1,
+                     (kind, cin, cout, ho, wo, ksize, {PTI_CONV_S1: "s1", PTI_CONV_S2PAD: "s2", PTI_CONV_UP2: "up2",
+                                                       PTI_CONV_ZINS: "zins"}[mode], n)))
     return y
 
 
-def _conv_kernel_name(ksize, mode, cin, cout, save=False, *, in_f16=False, out_f16=False, res=False, res_f16=False,
-                      prologue=PTI_PRO_NONE, gn=False, pool2=False, stats=False):
-    """Template instantiation the C side picks (mirrors pick_cout_tile / pick_ck / pick_ck2 and launch2_cfg's choice
-    of the storage-format / prologue specialisation), as rocprof names it."""
-    ct = 128 if cout % 128 == 0 else (64 if cout % 64 == 0 else 32)
-    ck = 128 if cin % 128 == 0 else (64 if cin % 64 == 0 else 32)
-    if mode == PTI_CONV_S2PAD:
-        return f"conv_mfma_kernel<3, 2, {min(ck, 64)}, {ct}>"
-    pxf = 4 if ct == 128 else 2
-    if in_f16 and out_f16 and (res_f16 or not res):
-        fm = 1
-    elif not in_f16 and not out_f16 and (not res_f16 or not res):
-        fm = 2
-    elif not in_f16 and not out_f16 and res_f16:
-        fm = 3
-    else:
-        fm = 0
-    fpro = PTI_PRO_GN_SILU if pxf == 4 else -1
-    if fm == 1 and prologue == PTI_PRO_GN_SILU and not gn and not pool2:
-        spec = (1, fpro)
-    elif save and ksize == 3:
-        spec = (0, -1)
-    elif fm == 1 and prologue == PTI_PRO_NONE and not gn and not pool2:
-        spec = (1, PTI_PRO_NONE)
-    elif fm == 2 and prologue == PTI_PRO_NONE and not gn and not stats:
-        spec = (2, PTI_PRO_NONE)
-    elif fm == 3 and prologue == PTI_PRO_NONE and gn and not stats and not pool2:
-        spec = (3, PTI_PRO_NONE)
-    else:
-        spec = (0, -1)
-    return f"conv_mfma2_kernel<{ksize}, {min(ck, ct)}, {ct}, {pxf}, {str(bool(save)).lower()}, {spec[0]}, {spec[1]}>"
-
-
-# Set to a list to make conv_mfma record (kernel name, algorithmic flops, bytes, start, end events) per
-# launch on the current stream — used by bench.py for the roofline line; None costs nothing.
+# Set to a list to make the MFMA conv / weight-gradient launchers record (kernel name, algorithmic flops, bytes, start
+# event, end event, shape) per launch on the current stream -- used by bench.py for the roofline line and its per-shape
+# table; None costs nothing.  The kernel name is the symbol the HIP runtime reports for the launch
+# (pti_last_kernel_name), shortened the way tools/pmc_traffic.py shortens rocprofv3's Kernel_Name column.
 KERNEL_PROFILE = None
+
+
+def last_kernel_name() -> str:
+    name = (L.lib().pti_last_kernel_name() or b"").decode()
+    name = name.replace("(anonymous namespace)::", "")
+    if name.startswith("void "):
+        name = name[5:]
+    depth = 0
+    for i, ch in enumerate(name):       # drop the trailing argument list, keep template arguments
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            return name[:i].strip()
+    return name.strip()
 
 
 def _strides4(t, layout):
@@ -304,27 +289,14 @@ def conv_wgrad_mfma(x, dy, dw, dbias, *, ksize=3, mode=PTI_CONV_S1, prologue=PTI
                                                  ws.numel() * 4, C.byref(d), C.byref(splits), _stream()),
             "pti_conv_wgrad_mfma_partials")
     e1.record()
+    name = last_kernel_name()
     L.check(L.lib().pti_conv_wgrad_reduce(_ptr(ws), splits.value, _ptr(dw), _ptr(dbias), int(accumulate), C.byref(d),
                                           _stream()), "pti_conv_wgrad_reduce")
     flops = 2.0 * n * ho * wo * cout * cin * ksize * ksize
-    # algorithmic bytes: x and dy read once (bf16); dw itself is negligible (the split-K slabs are not algorithmic)
-    prof.append((_wgrad_kernel_name(ksize, mode, cin, cout, n * ((ho + 7) // 8) * ((wo + 15) // 16), prologue, x.dtype == F16), flops,
-                 2.0 * (x.numel() + dy.numel()), e0, e1))
+    # algorithmic bytes: x and dy read once (16-bit); dw itself is negligible (the split-K slabs are not algorithmic)
+    prof.append((name, flops, 2.0 * (x.numel() + dy.numel()), e0, e1,
+                 ("conv wgrad", cin, cout, ho, wo, ksize, {PTI_CONV_S1: "s1", PTI_CONV_S2PAD: "s2", PTI_CONV_UP2: "up2"}[mode], n)))
     return dw
-
-
-def _wgrad_kernel_name(ksize, mode, cin, cout, ntiles, prologue=PTI_PRO_NONE, x_f16=False):
-    """Kernel symbol pti_conv_wgrad_mfma picks (mirrors its tile choice), as rocprof names it."""
-    if ksize == 3 and mode != PTI_CONV_S2PAD:
-        env = os.environ.get("PTI_WGRAD_COB")
-        cob = 2 if (cout % 64 == 0 and mode == PTI_CONV_S1 and env != "1" and (env == "2" or prologue != PTI_PRO_NONE)) else 1
-        plain = prologue == PTI_PRO_NONE and cob == 1
-        return f"wgrad_mfma3_kernel<{cob}, {str(plain).lower()}>"
-    co_t, ci_t = (64 if cout % 64 == 0 else 32), (64 if cin % 64 == 0 else 32)
-    if ntiles * (cout // co_t) * (cin // ci_t) < 16 * 512:
-        co_t = ci_t = 32
-    return (f"wgrad_mfma_kernel<{ksize}, {2 if mode == PTI_CONV_S2PAD else 1}, {co_t}, {ci_t}, "
-            f"{str(prologue == PTI_PRO_NONE).lower()}>")
 
 
 def wgrad_batch_eligible(x, dy, ksize, mode, prologue):
@@ -361,9 +333,9 @@ def conv_wgrad_mfma_batched(jobs, workspace=None, accumulate=True):
         e0.record()
     L.check(L.lib().pti_conv_wgrad_mfma_batched(arr, len(jobs), _ptr(ws), ws.numel() * 4, _stream()),
             "pti_conv_wgrad_mfma_batched")
-    if prof is not None:   # partial + reduction launches of the whole batch
+    if prof is not None:   # the partial launch + the (<1 % of the time) reduction launch of the whole batch
         e1.record()
-        prof.append(("wgrad_mfma4_kernel+wgrad_reduce4_kernel (batched)", flops, nbytes, e0, e1))
+        prof.append((last_kernel_name(), flops, nbytes, e0, e1, ("conv wgrad (batched)", 0, 0, 0, 0, 3, "s1", len(jobs))))
 
 
 def gn_bwd(x, da, dx, stats, gamma, beta, sums, dgamma, dbeta, *, groups, eps=1e-6, silu=True, dres=None):
@@ -417,12 +389,12 @@ def conv_mfma_gnbwd(dy_in, w_packed_t, gx, gstats, ggamma, gbeta, dy_out, gsums,
             "pti_conv2d_mfma_gnbwd")
     if prof is not None:
         e1.record()
+        name = last_kernel_name()
     L.check(L.lib().pti_gn_sums_finalize(_ptr(part), _ptr(gsums), n, tiles, 2 * cout, _stream()), "pti_gn_sums_finalize")
     if prof is not None:
-        prof.append((_conv_kernel_name(ksize, mode, cin, cout, in_f16=dy_in.dtype == F16, out_f16=dy_out.dtype == F16, res=True,
-                                       res_f16=gx.dtype == F16, gn=True),
-                     2.0 * n * ho * wo * cout * cin * ksize * ksize * (0.25 if mode == PTI_CONV_ZINS else 1.0),
-                     2.0 * (dy_in.numel() + 2 * dy_out.numel()), e0, e1))
+        prof.append((name, 2.0 * n * ho * wo * cout * cin * ksize * ksize * (0.25 if mode == PTI_CONV_ZINS else 1.0),
+                     2.0 * (dy_in.numel() + 2 * dy_out.numel()), e0, e1,
+                     ("conv dgrad+GN bwd", cin, cout, ho, wo, ksize, "zins" if mode == PTI_CONV_ZINS else "s1", n)))
     return dy_out
 
 
@@ -434,9 +406,17 @@ def gn_bwd_apply(x, dy, dx, stats, gamma, beta, sums, dgamma, dbeta, *, groups, 
     if dy.shape != x.shape or dx.shape != x.shape or (dres is not None and dres.shape != x.shape):
         raise ValueError("gn_bwd_apply: shape mismatch")
     _chk_stats(stats, n * groups * 2, "stats")
+    prof = KERNEL_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     L.check(L.lib().pti_gn_bwd_apply(_ptr(x), _ptr(dy), _ptr(dres), _ptr(dx), _ptr(stats), _ptr(gamma), _ptr(beta),
                                      _ptr(sums), _ptr(dgamma), _ptr(dbeta), n, h * w, c, groups, eps,
                                      int(x.dtype == F16), _stream()), "pti_gn_bwd_apply")
+    if prof is not None:   # pure HBM pass: reads x, dy (+ dres), writes dx; ~8 flops per element
+        e1.record()
+        prof.append((last_kernel_name(), 8.0 * x.numel(), 2.0 * x.numel() * (4 if dres is not None else 3), e0, e1,
+                     ("GroupNorm bwd apply", c, c, h, w, 0, "-", n)))
     return dx
 
 
