@@ -65,6 +65,12 @@ class VAEModel(nn.Module):
     def reconstruct_deterministic(self, x: torch.Tensor) -> torch.Tensor:
         return self.decode_stage_2_outputs(self.encode_deterministic(x))
 
+    def mark_weights_dirty(self) -> None:
+        """Not in the reference: tell the HIP engine to re-pack its 16-bit weight operands after a write the parameters'
+        version counters cannot see (``p.data.copy_()``, direct writes into the flat arena); see
+        ``AutoencoderKL.mark_weights_dirty``."""
+        self.autoencoder.mark_weights_dirty()
+
     # reference autoencoder.py:165-171 delegates to the inner net => un-prefixed keys.  The extra
     # (ignored-by-the-reference) arguments are accepted so parents' recursive state_dict() works.
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):

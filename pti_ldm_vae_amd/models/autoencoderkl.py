@@ -7,9 +7,9 @@ The ``nn.Module`` tree below only HOLDS parameters, under exactly the names MONA
 arithmetic runs in the HIP engine (``pti_ldm_vae_amd/engine.py``) through the C-ABI; there is no
 PyTorch or CPU fallback — calling the model on a CPU tensor raises.
 
-Memory layout: every parameter is a view into ONE flat fp32 arena (encoder+quant region first,
-post_quant+decoder region second); gradients are written by the kernels into a second arena of
-the same layout.  That is what lets the data-parallel loop all-reduce gradients as a few large
+Memory layout: every parameter is a view into ONE flat fp32 arena -- region 1 = encoder blocks, quant_conv_mu,
+quant_conv_log_sigma; region 2 = post_quant_conv, then the decoder blocks (registration order inside each, q|k|v
+projections adjacent) -- and gradients are written by the kernels into a second arena of the same layout.  That is what lets the data-parallel loop all-reduce gradients as a few large
 contiguous buckets and the optimiser run as one kernel.
 """
 from __future__ import annotations
@@ -178,7 +178,11 @@ class AutoencoderKL(nn.Module):
     def _build_arena(self):
         named = list(self.named_parameters())
         enc = [(n, p) for n, p in named if n.startswith(("encoder.", "quant_conv_"))]
-        dec = [(n, p) for n, p in named if n.startswith(("post_quant_conv.", "decoder."))]
+        # post_quant_conv sits FIRST in the decoder region (right behind quant_conv_*): backward finishes the decoder
+        # region with it, so its gradients merge into the bucket of decoder.blocks.0 and, across the region boundary,
+        # with the latent heads' that encode_backward reports first
+        dec = ([(n, p) for n, p in named if n.startswith("post_quant_conv.")] +
+               [(n, p) for n, p in named if n.startswith("decoder.")])
         assert len(enc) + len(dec) == len(named)
         order = _attn_first(enc) + _attn_first(dec)
         slots, off = {}, 0
@@ -235,7 +239,10 @@ class AutoencoderKL(nn.Module):
             p.grad = self.grad_view(name)
 
     def mark_weights_dirty(self):
-        """Call after updating the parameter arena outside autograd-visible in-place ops."""
+        """Call after updating weights in a way the parameters' version counters do not see.  The engine re-derives its
+        packed 16-bit operands when ``sum(p._version)`` changes: optimiser steps, ``load_state_dict``, ``p.add_()`` under
+        ``no_grad`` all bump it; writes through ``p.data`` (``p.data.copy_()``, EMA loops on ``.data``) or directly into
+        ``param_arena`` do NOT -- call this (or ``VAEModel.mark_weights_dirty``) after them."""
         if self._engine is not None:
             self._engine.packed_version = -1
 

@@ -42,7 +42,9 @@ from .utils.distributed import setup_ddp
 
 def parse_args(argv=None):
     p = argparse.ArgumentParser(description="VAE training on MI355X (HIP engine)")
-    p.add_argument("-c", "--config-file", default="./config/vae_dente_no_adv.json")
+    p.add_argument("-c", "--config-file", default="./config/vae_dente_recon_kl.json",
+                   help="default: the reference's vae_dente_no_adv.json with perceptual_weight 0 / adv off (the terms the HIP "
+                        "path does not provide); the reference configs themselves need --ignore-unavailable-terms")
     p.add_argument("-g", "--gpus", default=1, type=int)
     p.add_argument("--batch-size", type=int)
     p.add_argument("--lr", type=float)

@@ -159,3 +159,19 @@ def test_training_steps_are_bitwise_reproducible(dev, batch, size):
     for arena, losses in runs[1:]:
         assert losses == runs[0][1]
         assert torch.equal(arena, runs[0][0]), f"max |diff| {(arena - runs[0][0]).abs().max().item():.3e}"
+
+
+def test_p_data_writes_need_mark_weights_dirty(dev):
+    """``p.data.copy_()`` does not bump the parameter's version counter, so the packed operands stay stale
+    until ``mark_weights_dirty()`` -- documented behaviour, checked here both ways."""
+    m = _model(dev)
+    x = torch.randn(2, 1, 64, 64, device=dev)
+    with torch.no_grad():
+        r0 = m.reconstruct_deterministic(x)
+        w = m.autoencoder.decoder.blocks[1].conv1.conv.weight
+        w.data.mul_(0.0)                                   # through .data: invisible to the version counter
+        r_stale = m.reconstruct_deterministic(x)
+        assert torch.equal(r_stale, r0)                    # still the old packed weights
+        m.mark_weights_dirty()
+        r1 = m.reconstruct_deterministic(x)
+    assert (r1 - r0).abs().max().item() > 1e-4
