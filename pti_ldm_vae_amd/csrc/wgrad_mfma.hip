@@ -912,12 +912,12 @@ static bool w4_eligible(int n, int h, int w, int cin, int cout) {
 }
 // Pixel splits per job so that every workgroup of the launch streams about the same number of tiles and the launch has
 // about `wgs` workgroups; slab carving; reduction-block ranges; the XCD group lists.  One workgroup is resident per
-// CU (it owns the whole LDS); ~1024 workgroups = four rounds measured best inside the training step, where the launch
+// CU (it owns the whole LDS); ~2048 workgroups (planned; the 256-group cap usually binds first) measured best inside the training step, where the launch
 // shares the chip with the data-gradient chain on the other stream (same-box A/B: 256 13.45, 512 13.07, 1024 12.90,
 // 2048 12.73..12.87 ms per step); the 256-group cap of the XCD lists bounds it from above.
 // Returns the floats of workspace used, or -1 if it does not fit.
 static long long w4_plan(W4Batch& b, float* workspace, long long workspace_floats) {
-  static const int wgs_env = getenv("PTI_WGRAD_V4_WGS") ? atoi(getenv("PTI_WGRAD_V4_WGS")) : 1024;
+  static const int wgs_env = getenv("PTI_WGRAD_V4_WGS") ? atoi(getenv("PTI_WGRAD_V4_WGS")) : 2048;
   static const int diag_env = getenv("PTI_WGRAD_V4_DIAG") ? atoi(getenv("PTI_WGRAD_V4_DIAG")) : 0;
   b.diag = diag_env;
   auto tiles32 = [](const W4Job& a) { return (a.Cin / 32) * (a.Cout / 32); };
