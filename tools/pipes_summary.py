@@ -14,7 +14,7 @@ print("rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INS
       "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace -- python3 tools/pmc_conv.py <cin cout h w mode variant>")
 print("batch 32, fp16 storage + fp16 forward operands (the training step's formats); averages over 5 launches.")
 print("mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x duration x clock); valu_busy = 4 x SQ_ACTIVE_INST_VALU (quad-cycles) / same;")
-print("clock taken as SQ_BUSY_CYCLES-free estimate 2.1 GHz is NOT assumed: fractions use wave-cycle totals where possible.\n")
+print("(quad-cycles x 4 = cycles; both are sums over the 1024 SIMDs)\n")
 print(f"{'shape / variant':34s} {'kernel':46s} {'us':>7s} {'MFMA busy':>9s} {'VALU busy':>9s} {'wait':>6s} {'VALU/wave':>9s} {'TFLOP/s':>8s}")
 for d in sorted(glob.glob(os.path.join(out, "pipes_*"))):
     if not os.path.isdir(d):
