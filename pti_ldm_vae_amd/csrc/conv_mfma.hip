@@ -551,23 +551,34 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
     };
     if constexpr (!(SAVE && PXF == 2)) wload(wa, 0);   // (side-output variant at the 128-VGPR cap: after staging)
 
+    // Halo loads through a buffer descriptor with 32-bit byte offsets: an out-of-image (or zero-inserted, or
+    // past-the-tile) piece gets an offset beyond the descriptor's range and the hardware returns zeros -- no
+    // per-piece branch, no 64-bit address arithmetic (the generic-address form spent ~50 VALU instructions per piece,
+    // 18 of them quarter-rate v_mad_u64_u32, on kernels that are VALU-bound: ~1/5 of a narrow-layer tile's VALU work).
+    // The host guarantees x has fewer than 2^31 bytes.
     u32x4 raw[C::HITERS];
     bool ok[C::HITERS];
+    {
+      const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<bf16*>(a.x), 0, (unsigned)a.N * (unsigned)a.H * (unsigned)a.W * (unsigned)a.Cin * 2u, 0x00020000);
+      const unsigned base = ((unsigned)n * a.H * a.W * a.Cin + chunk * CK + lc * 8) * 2u;   // sample + channel piece
+      const unsigned rowb = (unsigned)a.W * a.Cin * 2u, pixb = (unsigned)a.Cin * 2u;
 #pragma unroll
-    for (int it = 0; it < C::HITERS; ++it) {
-      const int p = lp0 + it * PSTEP;
-      const int hy = p / C::HW, hx = p - hy * C::HW;
-      const int vy = vy0 + hy, vx = vx0 + hx;
-      bool v = (p < C::NP) && vy >= 0 && vy < VH && vx >= 0 && vx < VW;
-      int iy = vy, ix = vx;
-      if (twox) {
-        if (a.mode == PTI_CONV_ZINS) v = v && !((vy | vx) & 1);
-        iy = vy >> 1;
-        ix = vx >> 1;
+      for (int it = 0; it < C::HITERS; ++it) {
+        const int p = lp0 + it * PSTEP;
+        const int hy = p / C::HW, hx = p - hy * C::HW;
+        const int vy = vy0 + hy, vx = vx0 + hx;
+        bool v = (p < C::NP) && (unsigned)vy < (unsigned)VH && (unsigned)vx < (unsigned)VW;
+        int iy = vy, ix = vx;
+        if (twox) {
+          if (a.mode == PTI_CONV_ZINS) v = v && !((vy | vx) & 1);
+          iy = vy >> 1;
+          ix = vx >> 1;
+        }
+        ok[it] = v;
+        const unsigned off = v ? base + (unsigned)iy * rowb + (unsigned)ix * pixb : 0x80000000u;
+        raw[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0));
       }
-      ok[it] = v;
-      raw[it] = u32x4{0u, 0u, 0u, 0u};
-      if (v) raw[it] = *(const u32x4*)(a.x + ((size_t)(n * a.H + iy) * a.W + ix) * a.Cin + chunk * CK + lc * 8);
     }
     // GroupNorm scale / shift of this thread's 8 channels: fetched AFTER the halo loads were issued, so that the
     // statistics / gamma / beta round trips (L2) overlap the halo's HBM round trip instead of preceding it
@@ -1162,6 +1173,9 @@ static int conv2d_mfma_impl(const void* x, const void* w_packed, const float* bi
     a.g_inv_cnt = 1.0f / ((float)(d->cout / d->groups) * (float)d->ho * (float)d->wo);
     a.g_stats = (const stat_t*)gf->stats; a.g_gamma = gf->gamma; a.g_beta = gf->beta; a.g_sums = gf->sums;
   }
+  if (d->mode != PTI_CONV_S2PAD && (long long)d->n * d->h * d->w * d->cin * 2 >= (1ll << 31))
+    PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: input tensor of %lld bytes (the halo loads use 32-bit offsets: < 2 GiB)",
+             (long long)d->n * d->h * d->w * d->cin * 2);
   a.tiles_x = cdiv(d->wo, TW); a.tiles_y = cdiv(d->ho, TH);
   const int cout_tile = pick_cout_tile(d->cout);
   int rc, ck;
