@@ -642,6 +642,8 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
       if (ct == 0) {
         constexpr int PL = (KS - 1) / 2;
         constexpr int SITERS = C::TH2 * C::TW2 * C::NC / 256;
+        const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
+            a.act_out, 0, (unsigned)a.N * (unsigned)a.H * (unsigned)a.W * (unsigned)a.Cin * 2u, 0x00020000);
 #pragma unroll 1
         for (int it = 0; it < SITERS; ++it) {
           const int idx = tid + it * 256;
@@ -656,7 +658,8 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
               unpack8f(piece, f, true);
               piece = pack8(f);
             }
-            __builtin_nontemporal_store(piece, (u32x4*)(a.act_out + ((size_t)(n * a.H + vy) * a.W + vx) * a.Cin + chunk * CK + c8 * 8));
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bu32x4, piece), srs,
+                                                   ((unsigned)((n * a.H + vy) * a.W + vx) * a.Cin + chunk * CK + c8 * 8) * 2u, 0, 2 /* nt */);
           }
         }
       }
@@ -839,7 +842,10 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
     }
   }
   __syncthreads();
-  // (C) LDS tile -> global, 16 bytes per lane, consecutive lanes on consecutive addresses
+  // (C) LDS tile -> global, 16 bytes per lane, consecutive lanes on consecutive addresses (buffer stores with 32-bit
+  // offsets; non-temporal: the output is not re-read by this launch)
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+      a.y, 0, ((unsigned)a.N * (unsigned)a.Ho * (unsigned)a.Wo * (unsigned)a.Cout * 2u) >> (a.pool2 ? 2 : 0), 0x00020000);
   if ((FM == 0 || FM == 2) && a.pool2) {   // pooled output: plain data gradients only
     // data gradient of  conv(nearest-2x(x)): the gradient w.r.t. x is the 2x2 sum of the gradient w.r.t. the
     // up-sampled map -- summed here (fp32) from the LDS tile instead of writing the full-resolution map and
@@ -864,8 +870,8 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
         unpack8f(*(const u32x4*)(src + 17 * C::EPITCH), f_, out_f16);
 #pragma unroll
         for (int q = 0; q < 8; ++q) s_[q] += f_[q];
-        __builtin_nontemporal_store(pack8f(s_, out_f16),
-                                    (u32x4*)(a.y + ((size_t)(n * (a.Ho >> 1) + oy) * (a.Wo >> 1) + ox) * a.Cout + ct * CT + c8 * 8));
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bu32x4, pack8f(s_, out_f16)), yrs,
+                                               ((unsigned)((n * (a.Ho >> 1) + oy) * (a.Wo >> 1) + ox) * a.Cout + ct * CT + c8 * 8) * 2u, 0, 2);
       }
     }
   } else
@@ -875,8 +881,8 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
     const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
     if (oy < a.Ho && ox < a.Wo)
       // non-temporal: the output is not re-read by this launch; keeping it out of L2's way measured -1.1 % per step
-      __builtin_nontemporal_store(*(const u32x4*)(etile + p * C::EPITCH + epc * 16),
-                                  (u32x4*)(a.y + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.Cout + ct * CT + epc * 8));
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bu32x4, *(const u32x4*)(etile + p * C::EPITCH + epc * 16)), yrs,
+                                             ((unsigned)((n * a.Ho + oy) * a.Wo + ox) * a.Cout + ct * CT + epc * 8) * 2u, 0, 2);
   }
   if (gn_on) {
     if (tid < 2 * CT) {
@@ -1173,6 +1179,9 @@ static int conv2d_mfma_impl(const void* x, const void* w_packed, const float* bi
     a.g_inv_cnt = 1.0f / ((float)(d->cout / d->groups) * (float)d->ho * (float)d->wo);
     a.g_stats = (const stat_t*)gf->stats; a.g_gamma = gf->gamma; a.g_beta = gf->beta; a.g_sums = gf->sums;
   }
+  if ((long long)d->n * d->ho * d->wo * d->cout * 2 >= (1ll << 31))
+    PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: output tensor of %lld bytes (the stores use 32-bit offsets: < 2 GiB)",
+             (long long)d->n * d->ho * d->wo * d->cout * 2);
   if (d->mode != PTI_CONV_S2PAD && (long long)d->n * d->h * d->w * d->cin * 2 >= (1ll << 31))
     PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: input tensor of %lld bytes (the halo loads use 32-bit offsets: < 2 GiB)",
              (long long)d->n * d->h * d->w * d->cin * 2);
