@@ -92,11 +92,17 @@ def cpu_baseline(cfg_def, size, batch, steps):
                       f"reference's torch.set_num_threads(4)"}
 
 
+PMC_WORKLOAD = None   # "<config basename>:b<batch>:<size>" of this run; set by main()
+
+
 def _pmc():
+    """The committed counter passes, but only when they were taken on THIS workload (else None: a per-launch average
+    of another batch size / model would be paired with the wrong launches)."""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)))
     except (OSError, ValueError):
         return None
+    return pmc if pmc.get("workload") == PMC_WORKLOAD else None
 
 
 def roofline_from_profile(rec, steps):
@@ -271,6 +277,8 @@ def main():
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
 
+    global PMC_WORKLOAD
+    PMC_WORKLOAD = f"{os.path.basename(args.config)}:b{args.batch}:{args.size}"
     cfg = read_config(args.config)
     if "regressor_def" in cfg or "regression_train" in cfg:      # BASELINE config 5: regression on frozen latents
         return bench_regression(args, cfg, dev, world, rank, dist)

@@ -14,7 +14,7 @@ echo "== kernel trace"; rocprofv3 --kernel-trace --stats -d "$out/trace" --outpu
 echo "== pmc fetch";   rocprofv3 --pmc FETCH_SIZE -d "$out/pmc_fetch" --output-format csv -- python3 "$root/bench.py" --steps $STEPS --warmup $WARM --no-cpu-baseline > /dev/null 2> "$out/pmc_fetch.err"
 echo "== pmc write";   rocprofv3 --pmc WRITE_SIZE -d "$out/pmc_write" --output-format csv -- python3 "$root/bench.py" --steps $STEPS --warmup $WARM --no-cpu-baseline > /dev/null 2> "$out/pmc_write.err"
 # steps in a run: warm-up + timed + 4 host-enqueue probes + 2 instrumented
-python3 "$root/tools/pmc_traffic.py" "$out/pmc_fetch" "$out/pmc_write" "$out/${tag}_pmc_traffic.json" $((STEPS + WARM + 6)) "command: bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline (config A, batch 32, 256x256); steps profiled = warm-up + timed + 4 host-enqueue probes + 2 instrumented"
+python3 "$root/tools/pmc_traffic.py" "$out/pmc_fetch" "$out/pmc_write" "$out/${tag}_pmc_traffic.json" $((STEPS + WARM + 6)) "command: bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline (config A, batch 32, 256x256); steps profiled = warm-up + timed + 4 host-enqueue probes + 2 instrumented" "vae_dente_no_adv.json:b32:256"
 cp "$(find "$out/trace" -name '*kernel_stats.csv' | head -1)" "$out/${tag}_bench_b32_kernel_stats.csv"
 echo "== pipe counters per conv shape"
 CNT="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"

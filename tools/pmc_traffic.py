@@ -4,7 +4,8 @@
 launch and kernel.  gfx950 corrections per MI355X_MICROARCH.md (HBM / rocprofv3 section): counter unit is KB;
 FETCH_SIZE under-counts wide coalesced streams by 2x (128-B requests counted as 64 B), WRITE_SIZE is exact.
 
-usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json> <optimiser steps in the profiled run> ["note"]
+usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json> <optimiser steps in the profiled run> ["note"] ["workload key"]
+(the workload key -- "<config basename>:b<batch>:<size>" -- is what bench.py matches before it attaches these numbers)
 """
 import collections
 import csv
@@ -41,6 +42,7 @@ def main() -> None:
     fetch_dir, write_dir, out = sys.argv[1:4]
     steps = int(sys.argv[4])
     note = sys.argv[5] if len(sys.argv) > 5 else ""
+    workload = sys.argv[6] if len(sys.argv) > 6 else ""
     fetch, write = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
     kernels = {}
     for k in sorted(set(fetch) | set(write)):
@@ -51,7 +53,7 @@ def main() -> None:
     json.dump({"_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes).  Counter unit KB; fetch_bytes = "
                         "2 x FETCH_SIZE (gfx950 counts 128-B requests as 64 B for wide coalesced streams, "
                         "MI355X_MICROARCH.md HBM section); write_bytes = WRITE_SIZE.  Averages per launch.  " + note,
-               "steps_profiled": steps,
+               "workload": workload, "steps_profiled": steps,
                "bytes_per_step": round(sum((k["fetch_bytes"] + k["write_bytes"]) * k["launches_per_step"] for k in kernels.values())),
                "kernels": kernels}, open(out, "w"), indent=1)
     print(f"{len(kernels)} kernels -> {out}")
