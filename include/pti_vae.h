@@ -28,7 +28,7 @@ extern "C" {
 
 typedef void* pti_stream_t; /* hipStream_t */
 
-#define PTI_ABI_VERSION 2
+#define PTI_ABI_VERSION 3
 
 #define PTI_OK 0
 #define PTI_EINVAL (-1)   /* bad pointer / dimension */
@@ -289,6 +289,40 @@ int pti_cast_nhwc_bf16_to_nchw_f32(const void* x, float* y, int n, int c, int hw
  * doubles (zeroed here).                                                                                        */
 int pti_preprocess_batch(const float* src, const int64_t* offsets, const int32_t* hw, int b, int hp, int wp,
                          float* out, double* stats, pti_stream_t s);
+
+/* ---- PatchDiscriminator + adversarial loss --------------------------------------------------------
+ * Reference: vae_scripts/train_vae.py:266-279 (MONAI PatchDiscriminator(spatial_dims=2, num_layers_d=3, channels=32,
+ * in_channels=1, out_channels=1, norm="INSTANCE")), :298 (PatchAdversarialLoss("least_squares")), :399-401 (generator
+ * term), :447-458 (discriminator step).  A 4x4 convolution is lowered to patches x 1x1 convolution: the product, its
+ * data gradient and its weight gradient run on pti_conv2d_mfma / pti_conv_wgrad_mfma (ksize 1); the entry points below
+ * are the discriminator-specific passes.  Patches: bf16 [n][ho][wo][16*c], column = (ky*4 + kx)*c + channel,
+ * ho = (h + 2 - 4)/stride + 1.  Normalisation tables: float [n][c][2] = {mean, rstd} (InstanceNorm2d, biased variance).
+ * c in {32, 64, 128, 256}.  No floating-point atomics: results are bitwise reproducible.                              */
+/* fp32 image [n][h][w] (1 channel) -> patches [n][h/2][w/2][32]: 16 taps of the 4x4 stride-2 pad-1 window + 16 zeros. */
+int pti_pd_im2col_image(const float* img, void* patches, int n, int h, int w, pti_stream_t s);
+/* bf16 [n][h][w][c] -> patches of act(norm(src)): norm optional ({mean,rstd} table), act = LeakyReLU(slope) if `act`. */
+int pti_pd_im2col(const void* src, const float* norm, void* patches, int n, int h, int w, int c, int stride,
+                  int act, float slope, pti_stream_t s);
+/* nn.InstanceNorm2d statistics of y bf16 [n][hw][c] -> table [n][c][2] = {mean, 1/sqrt(var + eps)}. */
+int pti_pd_in_stats(const void* y, float* table, int n, int hw, int c, float eps, pti_stream_t s);
+/* Data gradient of pti_pd_im2col fused with LeakyReLU'(norm(y_prev)): g = act'(xhat) * col2im(d_patches), bf16
+ * [n][h][w][c]; with a norm table also writes the InstanceNorm-backward block partials {sum g, sum g*xhat}:
+ * partials float [n][pti_pd_col2im_blocks(n, h*w, c)][c][2], to be summed by pti_gn_sums_finalize(row_len = 2c).      */
+int pti_pd_col2im_blocks(int n, int hw, int c);
+int pti_pd_col2im(const void* d_patches, const void* y_prev, const float* norm, void* g, float* partials, int n,
+                  int h, int w, int c, int stride, float slope, pti_stream_t s);
+/* Gradient w.r.t. the 1-channel image from d_patches [n][h/2][w/2][32]: d_img = (accumulate ? d_img : 0) + scale * sum. */
+int pti_pd_col2im_image(const void* d_patches, float* d_img, int n, int h, int w, float scale, int accumulate,
+                        pti_stream_t s);
+/* InstanceNorm backward, second pass: dy = rstd * (g - sums[0]/hw - xhat * sums[1]/hw); sums float [n][c][2]; dy may be g. */
+int pti_pd_in_bwd_apply(const void* g, const void* y, const float* norm, const float* sums, void* dy, int n, int hw,
+                        int c, pti_stream_t s);
+/* PatchAdversarialLoss(criterion="least_squares"): *loss_out = mean((LeakyReLU_slope(logit) - target)^2) over `count`
+ * 16-bit logits (element m at logits[m*stride]; slope 0.05 = MONAI's default activation, 1 = none); when d_logits is
+ * given, row m of bf16 [count][stride] = {grad_scale * d(sum of squares)/d logit_m / 2 ... i.e. grad_scale * (a - target) *
+ * LeakyReLU'(logit), 0, ...}: pass grad_scale = weight * 2 / count for d(weight * loss).                               */
+int pti_pd_lsgan(const void* logits, int logits_f16, int stride, int count, float target, float slope,
+                 float grad_scale, float* loss_out, void* d_logits, pti_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -225,9 +225,13 @@ class AutoencoderKL(nn.Module):
             self._grad_arena = torch.zeros_like(self._arena)
         return self._grad_arena
 
-    def grad_view(self, name):
+    def slot_view(self, arena: torch.Tensor, name: str) -> torch.Tensor:
+        """The view of ``arena`` (parameter / gradient arena, an Adam moment buffer) with the parameter's shape."""
         o, n, shp = self._slots[name]
-        return self.grad_arena[o:o + n].view(shp)
+        return arena[o:o + n].view(shp)
+
+    def grad_view(self, name):
+        return self.slot_view(self.grad_arena, name)
 
     def arena_regions(self):
         """(encoder+quant region, post_quant+decoder region) as (start, end) element offsets."""

@@ -616,3 +616,103 @@ def preprocess_batch(src, offsets, hw, out, stats=None):
     L.check(L.lib().pti_preprocess_batch(_ptr(src), _ptr(offsets), _ptr(hw), b, hp, wp, _ptr(out), _ptr(stats), _stream()),
             "pti_preprocess_batch")
     return out
+
+
+# ---- PatchDiscriminator passes (csrc/discriminator.hip; include/pti_vae.h "PatchDiscriminator") -----------------------
+def pd_out_hw(h, w, stride):
+    return (h + 2 - 4) // stride + 1, (w + 2 - 4) // stride + 1
+
+
+def pd_im2col_image(img, patches):
+    """img fp32 [B,1,H,W] (or [B,H,W]) -> patches bf16 [B,H/2,W/2,32] of the 4x4 stride-2 pad-1 window (+16 zero columns)."""
+    _chk(img, F32, "img")
+    _chk(patches, BF16, "patches", 4)
+    b, h, w = img.shape[0], img.shape[-2], img.shape[-1]
+    if img.numel() != b * h * w or tuple(patches.shape) != (b, h // 2, w // 2, 32):
+        raise ValueError(f"pd_im2col_image: img {tuple(img.shape)} / patches {tuple(patches.shape)}")
+    L.check(L.lib().pti_pd_im2col_image(_ptr(img), _ptr(patches), b, h, w, _stream()), "pti_pd_im2col_image")
+    return patches
+
+
+def pd_im2col(src, norm, patches, *, stride, act=True, slope=0.2):
+    _chk(src, BF16, "src", 4)
+    _chk(patches, BF16, "patches", 4)
+    n, h, w, c = src.shape
+    ho, wo = pd_out_hw(h, w, stride)
+    if tuple(patches.shape) != (n, ho, wo, 16 * c):
+        raise ValueError(f"pd_im2col: patches {tuple(patches.shape)} != {(n, ho, wo, 16 * c)}")
+    if norm is not None:
+        _chk(norm, F32, "norm")
+        if norm.numel() != n * c * 2:
+            raise ValueError("pd_im2col: norm table size")
+    L.check(L.lib().pti_pd_im2col(_ptr(src), _ptr(norm), _ptr(patches), n, h, w, c, stride, int(act), float(slope), _stream()),
+            "pti_pd_im2col")
+    return patches
+
+
+def pd_in_stats(y, eps=1e-5, table=None):
+    _chk(y, BF16, "y", 4)
+    n, h, w, c = y.shape
+    if table is None:
+        table = torch.empty(n, c, 2, dtype=F32, device=y.device)
+    L.check(L.lib().pti_pd_in_stats(_ptr(y), _ptr(table), n, h * w, c, float(eps), _stream()), "pti_pd_in_stats")
+    return table
+
+
+def pd_col2im(d_patches, y_prev, norm, g, *, stride, slope=0.2):
+    """-> (g, sums [n,c,2] | None): g = LeakyReLU'(norm(y_prev)) * col2im(d_patches); with ``norm`` also the
+    InstanceNorm-backward sums {sum g, sum g*xhat} (block partials folded in fixed order by pti_gn_sums_finalize)."""
+    _chk(d_patches, BF16, "d_patches", 4)
+    _chk(y_prev, BF16, "y_prev", 4)
+    _chk(g, BF16, "g", 4)
+    n, h, w, c = y_prev.shape
+    ho, wo = pd_out_hw(h, w, stride)
+    if tuple(d_patches.shape) != (n, ho, wo, 16 * c) or g.shape != y_prev.shape:
+        raise ValueError(f"pd_col2im: d_patches {tuple(d_patches.shape)} for y_prev {tuple(y_prev.shape)} stride {stride}")
+    part = sums = None
+    if norm is not None:
+        _chk(norm, F32, "norm")
+        bps = L.lib().pti_pd_col2im_blocks(n, h * w, c)
+        part = torch.empty(n, bps, c, 2, dtype=F32, device=g.device)
+    L.check(L.lib().pti_pd_col2im(_ptr(d_patches), _ptr(y_prev), _ptr(norm), _ptr(g), _ptr(part), n, h, w, c, stride,
+                                  float(slope), _stream()), "pti_pd_col2im")
+    if part is not None:
+        sums = torch.empty(n, c, 2, dtype=F32, device=g.device)
+        L.check(L.lib().pti_gn_sums_finalize(_ptr(part), _ptr(sums), n, part.shape[1], 2 * c, _stream()), "pti_gn_sums_finalize")
+    return g, sums
+
+
+def pd_col2im_image(d_patches, d_img, *, scale=1.0, accumulate=False):
+    _chk(d_patches, BF16, "d_patches", 4)
+    _chk(d_img, F32, "d_img")
+    n, ho, wo, k = d_patches.shape
+    if k != 32 or d_img.numel() != n * 4 * ho * wo:
+        raise ValueError("pd_col2im_image: shapes")
+    L.check(L.lib().pti_pd_col2im_image(_ptr(d_patches), _ptr(d_img), n, 2 * ho, 2 * wo, float(scale), int(accumulate),
+                                        _stream()), "pti_pd_col2im_image")
+    return d_img
+
+
+def pd_in_bwd_apply(g, y, norm, sums, dy=None):
+    _chk(g, BF16, "g", 4)
+    _chk(y, BF16, "y", 4)
+    n, h, w, c = y.shape
+    dy = g if dy is None else dy
+    L.check(L.lib().pti_pd_in_bwd_apply(_ptr(g), _ptr(y), _ptr(norm), _ptr(sums), _ptr(dy), n, h * w, c, _stream()),
+            "pti_pd_in_bwd_apply")
+    return dy
+
+
+def pd_lsgan(logits_rows, *, target, slope=0.05, grad_scale=0.0, loss_out, d_logits=None):
+    """logits_rows: 16-bit [M, stride] (the logit is column 0).  Writes mean((LeakyReLU_slope(l) - target)^2) to the
+    one-element fp32 ``loss_out``; ``d_logits`` (bf16, same shape) gets grad_scale * (a - target) * LeakyReLU'(l) in
+    column 0 and zeros elsewhere."""
+    _chk(logits_rows, ACT16, "logits", 2)
+    m, stride = logits_rows.shape
+    if d_logits is not None:
+        _chk(d_logits, BF16, "d_logits", 2)
+        if d_logits.shape != logits_rows.shape:
+            raise ValueError("pd_lsgan: d_logits shape")
+    L.check(L.lib().pti_pd_lsgan(_ptr(logits_rows), int(logits_rows.dtype == F16), stride, m, float(target), float(slope),
+                                 float(grad_scale), _ptr(loss_out), _ptr(d_logits), _stream()), "pti_pd_lsgan")
+    return loss_out

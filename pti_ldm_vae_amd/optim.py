@@ -1,5 +1,6 @@
-"""``FlatAdam`` — ``torch.optim.Adam`` (defaults; reference ``vae_scripts/train_vae.py:301``) as ONE HIP
-kernel over the model's flat fp32 parameter arena instead of ~220 per-tensor updates.
+"""``FlatAdam`` — ``torch.optim.Adam`` (defaults; reference ``vae_scripts/train_vae.py:301,304``) as ONE HIP
+kernel over a model's flat fp32 parameter arena (``AutoencoderKL``: instead of ~220 per-tensor updates;
+``PatchDiscriminator``: the same kernel over its arena).
 
 ``state_dict()`` / ``load_state_dict()`` use ``torch.optim.Adam``'s format over ``VAEModel.parameters()``
 order, so ``checkpoint_epoch*.pth`` files (train_vae.py:752-765) are interchangeable with the
@@ -40,10 +41,9 @@ class FlatAdam:
         state = {}
         if self.step_count > 0:
             for i, (n, p) in enumerate(self._ordered()):
-                o, cnt, shp = self.net._slots[n]
                 state[i] = {"step": torch.tensor(float(self.step_count)),
-                            "exp_avg": self.exp_avg[o:o + cnt].view(shp).clone(),
-                            "exp_avg_sq": self.exp_avg_sq[o:o + cnt].view(shp).clone()}
+                            "exp_avg": self.net.slot_view(self.exp_avg, n).clone(memory_format=torch.contiguous_format),
+                            "exp_avg_sq": self.net.slot_view(self.exp_avg_sq, n).clone(memory_format=torch.contiguous_format)}
         group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": 0, "amsgrad": False,
                  "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
                  "decoupled_weight_decay": False, "params": list(range(len(self._ordered())))}
@@ -60,7 +60,6 @@ class FlatAdam:
             st = sd["state"].get(i)
             if st is None:
                 continue
-            o, cnt, _ = self.net._slots[n]
-            self.exp_avg[o:o + cnt].copy_(st["exp_avg"].reshape(-1))
-            self.exp_avg_sq[o:o + cnt].copy_(st["exp_avg_sq"].reshape(-1))
+            self.net.slot_view(self.exp_avg, n).copy_(st["exp_avg"])
+            self.net.slot_view(self.exp_avg_sq, n).copy_(st["exp_avg_sq"])
             self.step_count = int(float(st["step"]))

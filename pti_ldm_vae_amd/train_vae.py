@@ -12,9 +12,13 @@ rank-local validation means, best checkpoint chosen on rank 0's recon loss).
 What is different, on purpose:
   * the step runs on the HIP engine through ``VAETrainer`` (no autograd tape, no DDP wrapper, no
     unused-parameter search, no ``detect_anomaly``; ``--detect-anomaly`` is not needed without a tape);
-  * the perceptual (LPIPS) and adversarial terms are NOT available here (they need packages/weights that are
-    not installable offline): ``perceptual_weight`` and ``adv_enabled`` are read and reported, and must be
-    0/false — or pass ``--ignore-unavailable-terms`` to train with recon + KL (+ AR-VAE) and a warning;
+  * the adversarial branch (``adv_enabled``: PatchDiscriminator + least-squares PatchAdversarialLoss, active from epoch
+    6 on, train_vae.py:266-279,399-401,447-458) runs natively (``models/patch_discriminator.py``, ``disc_engine.py``);
+    ``discriminator_last.pt`` / ``discriminator_epoch{E}.pth`` and the ``discriminator_state_dict`` /
+    ``optimizer_d_state_dict`` checkpoint entries are written and read like the reference's;
+  * the perceptual (LPIPS) term is NOT available here (it needs packages/weights that are not installable offline):
+    ``perceptual_weight`` is read and reported, and must be 0 — or pass ``--ignore-unavailable-terms`` to train
+    without it and a warning;
   * the AR-VAE term (``regularized_attributes``) IS part of the native step (``pti_ar_vae_loss``);
   * data: without ``--synthetic`` the TIFF directory of the config is read through the device input pipeline
     (``pti_ldm_vae_amd.data``: host decode -> one H2D copy -> GPU resize + masked z-score; attribute JSONs joined
@@ -34,7 +38,7 @@ from pathlib import Path
 
 import torch
 
-from .models import VAEModel, compute_total_loss
+from .models import PatchDiscriminator, VAEModel, compute_total_loss
 from .trainer import ARSettings, VAETrainer, prepare_batch
 from .utils import read_config, resolve_ar_settings
 from .utils.distributed import setup_ddp
@@ -43,8 +47,8 @@ from .utils.distributed import setup_ddp
 def parse_args(argv=None):
     p = argparse.ArgumentParser(description="VAE training on MI355X (HIP engine)")
     p.add_argument("-c", "--config-file", default="./config/vae_dente_recon_kl.json",
-                   help="default: the reference's vae_dente_no_adv.json with perceptual_weight 0 / adv off (the terms the HIP "
-                        "path does not provide); the reference configs themselves need --ignore-unavailable-terms")
+                   help="default: the reference's vae_dente_no_adv.json with perceptual_weight 0 (the LPIPS term the HIP path "
+                        "does not provide); the reference configs themselves need --ignore-unavailable-terms")
     p.add_argument("-g", "--gpus", default=1, type=int)
     p.add_argument("--batch-size", type=int)
     p.add_argument("--lr", type=float)
@@ -56,6 +60,8 @@ def parse_args(argv=None):
     p.add_argument("--synthetic", type=int, default=0, help="train on N synthetic images (no file I/O)")
     p.add_argument("--log-every", type=int, default=20)
     p.add_argument("--ignore-unavailable-terms", action="store_true")
+    p.add_argument("--adv-start-epoch", type=int, default=6,
+                   help="first epoch with the adversarial branch on (the reference hard-codes `epoch > 5`)")
     p.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     return p.parse_args(argv)
 
@@ -147,12 +153,17 @@ class TiffShards:
         yield from loader
 
 
-def save_checkpoints(args, model, opt, epoch, val_loss, best_val_loss, best_epoch_saved, total_step, rank):
+def save_checkpoints(args, model, opt, epoch, val_loss, best_val_loss, best_epoch_saved, total_step, rank, disc=None,
+                     opt_d=None):
     """train_vae.py:675-769: always ``autoencoder_last.pt``; on improvement replace the best files."""
     if rank != 0:
         return best_val_loss, best_epoch_saved
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     torch.save(sd, os.path.join(args.model_dir, "autoencoder_last.pt"))
+    dsd = None
+    if disc is not None:
+        dsd = {k: v.detach().cpu() for k, v in disc.state_dict().items()}
+        torch.save(dsd, os.path.join(args.model_dir, "discriminator_last.pt"))
     if val_loss >= best_val_loss:
         return best_val_loss, best_epoch_saved
     if best_epoch_saved is not None:
@@ -161,17 +172,23 @@ def save_checkpoints(args, model, opt, epoch, val_loss, best_val_loss, best_epoc
             if os.path.exists(f):
                 os.remove(f)
     torch.save(sd, os.path.join(args.model_dir, f"autoencoder_epoch{epoch}.pth"))
-    osd = opt.state_dict()
-    for st in osd["state"].values():
-        st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"].cpu(), st["exp_avg_sq"].cpu()
-    torch.save({"epoch": epoch, "autoencoder_state_dict": sd, "discriminator_state_dict": None,
-                "optimizer_g_state_dict": osd, "optimizer_d_state_dict": None, "best_val_loss": val_loss,
+    if dsd is not None:
+        torch.save(dsd, os.path.join(args.model_dir, f"discriminator_epoch{epoch}.pth"))
+
+    def host(osd):
+        for st in osd["state"].values():
+            st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"].cpu(), st["exp_avg_sq"].cpu()
+        return osd
+    osd = host(opt.state_dict())
+    torch.save({"epoch": epoch, "autoencoder_state_dict": sd, "discriminator_state_dict": dsd,
+                "optimizer_g_state_dict": osd, "optimizer_d_state_dict": host(opt_d.state_dict()) if opt_d is not None else None,
+                "best_val_loss": val_loss,
                 "total_step": total_step}, os.path.join(args.model_dir, f"checkpoint_epoch{epoch}.pth"))
     print(f"Best models saved for epoch {epoch}")
     return val_loss, epoch
 
 
-def load_checkpoint(args, model, opt, device):
+def load_checkpoint(args, model, opt, device, disc=None, opt_d=None):
     """train_vae.py:309-339 (with map_location fixed, Appendix D); ``checkpoint_dir`` is a FILE path."""
     if not args.resume_ckpt:
         print("[INFO] Training from scratch")
@@ -182,6 +199,10 @@ def load_checkpoint(args, model, opt, device):
     ck = torch.load(path, map_location=device, weights_only=True)
     model.load_state_dict(ck["autoencoder_state_dict"])
     opt.load_state_dict(ck["optimizer_g_state_dict"])
+    if disc is not None and ck.get("discriminator_state_dict") is not None:     # train_vae.py:320-331
+        disc.load_state_dict(ck["discriminator_state_dict"])
+        if opt_d is not None and ck.get("optimizer_d_state_dict") is not None:
+            opt_d.load_state_dict(ck["optimizer_d_state_dict"])
     print(f"[INFO] Resuming from epoch {ck['epoch'] + 1} | best_val_loss = {ck['best_val_loss']:.4f}")
     return ck["epoch"] + 1, ck["best_val_loss"], ck["total_step"], ck["epoch"]
 
@@ -196,14 +217,12 @@ def main(argv=None):
     unavailable = []
     if float(tr.get("perceptual_weight", 0.0)) != 0.0:
         unavailable.append(f"perceptual_weight={tr['perceptual_weight']} (LPIPS needs lpips+torchvision+weights)")
-    if adv_enabled:
-        unavailable.append("adv_enabled=true (PatchDiscriminator branch, active after epoch 5)")
     if unavailable:
         msg = "terms not available in the native trainer: " + "; ".join(unavailable)
         if not args.ignore_unavailable_terms:
             raise SystemExit(msg + " — set them to 0/false or pass --ignore-unavailable-terms")
         if rank == 0:
-            print("[WARN] " + msg + " — training with recon + kl_weight*KL only")
+            print("[WARN] " + msg + " — training without them")
     if rank == 0:
         run_dir = Path(args.run_dir)
         if run_dir.exists() and not args.resume_ckpt:
@@ -218,9 +237,14 @@ def main(argv=None):
     pg = None
     reg_attrs = getattr(args, "regularized_attributes", {}) or {}
     ar = ARSettings.from_config(reg_attrs, ar_gamma, args.autoencoder_def["latent_channels"]) if ar_enabled else None
+    # create_models (train_vae.py:266-279): the discriminator exists whenever adv_enabled; it is used from epoch 6 on
+    disc = PatchDiscriminator(spatial_dims=2, num_layers_d=3, channels=32, in_channels=1, out_channels=1,
+                              norm="INSTANCE").to(device) if adv_enabled else None
+    adv_weight = float(tr.get("adv_weight", 0.0))
     trainer = VAETrainer(model, lr=tr["lr"], world_size=world, process_group=pg, recon_loss=tr.get("recon_loss", "l1"),
-                         kl_weight=tr["kl_weight"], rank_eps_offset=rank, ar=ar)
-    start_epoch, best_val, total_step, best_epoch_saved = load_checkpoint(args, model, trainer.opt, device)
+                         kl_weight=tr["kl_weight"], rank_eps_offset=rank, ar=ar, discriminator=disc, adv_weight=adv_weight)
+    opt_d = trainer.opt_d if disc is not None else None
+    start_epoch, best_val, total_step, best_epoch_saved = load_checkpoint(args, model, trainer.opt, device, disc, opt_d)
     model.autoencoder.mark_weights_dirty()
     if args.synthetic:
         n = args.subset_size or args.synthetic
@@ -246,15 +270,18 @@ def main(argv=None):
     for epoch in range(start_epoch, max_epochs):
         t0 = time.time()
         seen = 0
+        adv_on = disc is not None and epoch >= args.adv_start_epoch      # reference: adv_enabled and epoch > 5
         for step, batch in enumerate(data.batches(epoch, train=True)):
             images, attrs = prepare_batch(batch, device, ar_enabled)
-            out = trainer.step(images, attributes=attrs)
+            out = trainer.step(images, attributes=attrs, adversarial=adv_on)
             total_step += 1
             seen += images.shape[0]
             if log is not None and step % args.log_every == 0:
                 rec = {"train/step": total_step, "train/recon_loss": out["recon"].item(),
                        "train/kl_loss": out["kl"].item(), "train/loss_total": out["loss"].item(),
-                       "train/perceptual_loss": 0.0, "train/adv_gen_loss": 0.0, "train/adv_disc_loss": 0.0}
+                       "train/perceptual_loss": 0.0,      # W&B names and weighting of train_vae.py:467-468
+                       "train/adv_gen_loss": adv_weight * out["adv_gen"].item() if adv_on else 0.0,
+                       "train/adv_disc_loss": adv_weight * out["adv_disc"].item() if adv_on else 0.0}
                 if ar is not None:   # W&B names of train_vae.py:471-478
                     rec["train/ar_loss_total"] = out["ar"].item()
                     for name, la, cnt, dl in zip(ar.names, out["ar_per_attr"].tolist(), out["ar_pairs"].tolist(), ar.deltas):
@@ -262,17 +289,20 @@ def main(argv=None):
                 log.write(json.dumps(rec) + "\n")
                 log.flush()
         if epoch % val_interval == 0:
-            rsum = ksum = asum = torch.zeros((), device=device)
+            rsum = ksum = asum = gsum = torch.zeros((), device=device)
             nb = 0
             for batch in data.batches(epoch, train=False):
                 images, attrs = prepare_batch(batch, device, ar_enabled)
-                v, _ = trainer.eval_losses(images, attributes=attrs)
+                v, _ = trainer.eval_losses(images, attributes=attrs, adversarial=adv_on)
                 rsum, ksum, nb = rsum + v["recon"], ksum + v["kl"], nb + 1
+                if adv_on:
+                    gsum = gsum + v["adv_gen"]
                 if ar is not None:
                     asum = asum + v["ar"]
-            val_recon, val_kl, val_ar = ((t / max(nb, 1)).item() for t in (rsum, ksum, asum))
-            val_total = compute_total_loss(val_recon, val_kl, 0.0, 0.0, val_ar, kl_weight=kl_w, perceptual_weight=0.0,
-                                           adv_weight=0.0, ar_gamma=ar_gamma, ar_vae_enabled=ar_enabled)
+            val_recon, val_kl, val_ar, val_gen = ((t / max(nb, 1)).item() for t in (rsum, ksum, asum, gsum))
+            val_total = compute_total_loss(val_recon, val_kl, 0.0, val_gen, val_ar, kl_weight=kl_w, perceptual_weight=0.0,
+                                           adv_weight=adv_weight if adv_on else 0.0, ar_gamma=ar_gamma,
+                                           ar_vae_enabled=ar_enabled)
             torch.cuda.synchronize()
             dt = time.time() - t0
             if rank == 0:
@@ -284,7 +314,7 @@ def main(argv=None):
                 log.write(json.dumps(rec) + "\n")
                 log.flush()
             best_val, best_epoch_saved = save_checkpoints(args, model, trainer.opt, epoch, val_recon, best_val,
-                                                          best_epoch_saved, total_step, rank)
+                                                          best_epoch_saved, total_step, rank, disc, opt_d)
     if log is not None:
         log.close()
     if ddp:

@@ -9,10 +9,12 @@ may hand over (tensor / ``(images, attributes)`` / list of ``(image, attributes)
 device tensors.  The AR-VAE term (``compute_ar_vae_loss``, losses.py:69-166, called at train_vae.py:408-415 on
 ``z_mu.mean(dim=(2, 3))``) runs as one HIP kernel (``pti_ar_vae_loss``) that also adds its gradient to ``d z_mu``.
 
-Perceptual (LPIPS) and adversarial terms are NOT part of this path (unavailable offline / inactive
-before epoch 6 -- SURVEY.md 2); ``perceptual_weight`` must be 0 here and the drop-in autograd path
-(``VAEModel.forward`` + any torch loss) remains available for everything else.  No ``.item()`` on
-the step path: loss scalars come back as device tensors.
+The adversarial branch (train_vae.py:399-401 generator term, :447-458 discriminator step; active when ``adv_enabled``
+and ``epoch > 5``) runs on the PatchDiscriminator engine (``disc_engine.py``): pass ``discriminator=`` /
+``adv_weight=`` and call ``step(..., adversarial=True)``.  The perceptual (LPIPS) term is NOT part of this path
+(weights unavailable offline -- DESIGN.md 6); ``perceptual_weight`` must be 0 here and the drop-in autograd path
+(``VAEModel.forward`` + any torch loss) remains available for everything else.  No ``.item()`` on the step path: loss
+scalars come back as device tensors.
 """
 from __future__ import annotations
 
@@ -105,7 +107,8 @@ class ARSettings:
 class VAETrainer:
     def __init__(self, model, *, lr: float, world_size: int = 1, process_group=None, recon_loss: str = "l1",
                  kl_weight: float = 1e-3, kl_input_is_logvar: bool = True, bucket_bytes: int = 4 << 20,
-                 rank_eps_offset: int = 0, ar: ARSettings | None = None):
+                 rank_eps_offset: int = 0, ar: ARSettings | None = None, discriminator=None, adv_weight: float = 0.0,
+                 lr_d: float | None = None, adv_no_activation_leastsq: bool = False):
         self.model = model
         self.net = net = model.autoencoder
         self.eng = net.engine()
@@ -130,6 +133,18 @@ class VAETrainer:
         # the GPU always has the next step queued, the host never gets further ahead than that.
         self.max_steps_in_flight = int(os.environ.get("PTI_MAX_STEPS_IN_FLIGHT", "2"))
         self._step_done = collections.deque()
+        # adversarial branch: PatchDiscriminator with its own flat Adam (train_vae.py:304: same lr x world) and its own
+        # gradient exchange (one bucket: the discriminator is 2.8 MB of fp32 gradients)
+        self.disc, self.adv_weight = discriminator, float(adv_weight)
+        # PatchAdversarialLoss("least_squares"): LeakyReLU(0.05) on the logits unless no_activation_leastsq (MONAI's option)
+        self.adv_slope = 1.0 if adv_no_activation_leastsq else 0.05
+        if discriminator is not None:
+            self.disc_eng = discriminator.engine()
+            discriminator.attach_grads()
+            self.opt_d = FlatAdam(discriminator, (lr if lr_d is None else lr_d) * world_size)
+            self.reducer_d = FlatGradAllReducer(discriminator.grad_arena, process_group, bucket_bytes)
+            broadcast_parameters(discriminator.param_arena, process_group)
+            discriminator.mark_weights_dirty()
         self.ar = ar
         if ar is not None:
             if max(ar.channels) >= net.latent_channels:
@@ -174,11 +189,51 @@ class VAETrainer:
         ops.ar_vae_loss(mu, table, self._ar_ch, self._ar_delta, per, cnt, gamma=self.ar.gamma, d_mu=d_mu, pair_mask=mask)
         return per.sum(), per, cnt
 
-    def step(self, images: torch.Tensor, eps: torch.Tensor | None = None, attributes: dict | None = None):
+    # ---- adversarial branch -----------------------------------------------------------------------------------------
+    def _adv_generator_term(self, recon, d_recon):
+        """train_vae.py:399-401: adv_loss(discriminator(recon)[-1], target_is_real=True, for_discriminator=False); adds
+        adv_weight * its gradient into ``d_recon`` (when given).  Returns (loss, the pass's context)."""
+        eng = self.disc_eng
+        ctx = eng.forward(recon, save=d_recon is not None)
+        loss, d = eng.lsgan(ctx, target_is_real=True, weight=self.adv_weight, want_grad=d_recon is not None,
+                            slope=self.adv_slope)
+        if d_recon is not None:
+            eng.backward(ctx, d, want_wgrad=False, d_img=d_recon, accumulate_dx=True)
+        return loss, ctx
+
+    def _adv_discriminator_losses(self, fake_ctx, images, train: bool):
+        """train_vae.py:447-458: 0.5 * (adv_loss(D(recon.detach()), fake) + adv_loss(D(images), real)); the fake pass is
+        the generator term's (the discriminator's weights have not changed in between).  ``train``: also the backward
+        passes, gradient exchange and the discriminator's Adam step on adv_weight * that loss."""
+        eng, disc = self.disc_eng, self.disc
+        if train:
+            disc.grad_arena.zero_()
+            self.reducer_d.begin_step()
+        l_fake, d_fake = eng.lsgan(fake_ctx, target_is_real=False, weight=0.5 * self.adv_weight, want_grad=train,
+                                   slope=self.adv_slope)
+        if train:
+            eng.backward(fake_ctx, d_fake, want_wgrad=True)
+        real_ctx = eng.forward(images.float(), save=train)
+        l_real, d_real = eng.lsgan(real_ctx, target_is_real=True, weight=0.5 * self.adv_weight, want_grad=train,
+                                   slope=self.adv_slope)
+        if train:
+            eng.backward(real_ctx, d_real, want_wgrad=True)
+            if self.world > 1:
+                self.reducer_d.ready(0, disc.grad_arena.numel())
+            self.reducer_d.finish()
+            self.opt_d.step(grad_scale=1.0 / self.world)
+        return 0.5 * (l_fake + l_real)
+
+    def step(self, images: torch.Tensor, eps: torch.Tensor | None = None, attributes: dict | None = None,
+             adversarial: bool = False):
         """One optimiser step on ``images`` [B,C,H,W] fp32 (already on the device).  Returns a dict of
         DEVICE scalars {"loss", "recon", "kl"} -- plus {"ar", "ar_per_attr", "ar_pairs"} (names: ``self.ar.names``) when
         the AR-VAE term is on, which needs ``attributes`` = {name: [B] tensor} -- with no host sync with THIS step
-        (see ``max_steps_in_flight``)."""
+        (see ``max_steps_in_flight``).  ``adversarial`` (the reference's ``adv_enabled and epoch > 5``): the generator
+        loss gains adv_weight * the least-squares term through the discriminator, then the discriminator takes its
+        own optimiser step; adds {"adv_gen", "adv_disc"} (unweighted, as the reference logs them before weighting)."""
+        if adversarial and self.disc is None:
+            raise ValueError("step(adversarial=True) needs VAETrainer(discriminator=...)")
         net, eng, red = self.net, self.eng, self.reducer
         while len(self._step_done) >= max(1, self.max_steps_in_flight):
             self._step_done.popleft().synchronize()
@@ -199,6 +254,9 @@ class VAETrainer:
             ar_out = None
             if self.ar is not None:   # + gamma * AR-VAE(z_mu.mean(h, w)): its gradient goes straight into d_mu
                 ar_out = self._ar_term(mu, attributes, d_mu)
+            adv_ctx = None
+            if adversarial:           # + adv_weight * generator term: its gradient w.r.t. the reconstruction joins d_recon
+                adv_gen, adv_ctx = self._adv_generator_term(recon, d_recon)
             dz = eng.decode_backward(c_dec, d_recon, want_dz=True, join=False)   # encode_backward joins the side stream
             # z = mu + eps*sigma ; third = sigma (or 2 log sigma)
             d_sigma = d_third if net.third_output == "sigma" else d_third * (2.0 / sigma)
@@ -209,6 +267,7 @@ class VAETrainer:
         finally:
             eng.grad_ready_cb = None
         self.opt.step(grad_scale=1.0 / self.world)
+        adv_disc = self._adv_discriminator_losses(adv_ctx, images, train=True) if adversarial else None
         done = torch.cuda.Event()
         done.record()
         self._step_done.append(done)
@@ -216,13 +275,16 @@ class VAETrainer:
         if ar_out is not None:
             res["ar"], res["ar_per_attr"], res["ar_pairs"] = ar_out
             res["loss"] = res["loss"] + self.ar.gamma * ar_out[0]
+        if adversarial:
+            res["adv_gen"], res["adv_disc"] = adv_gen[0], adv_disc[0]
+            res["loss"] = res["loss"] + self.adv_weight * adv_gen[0]
         return res
 
     @torch.no_grad()
-    def eval_losses(self, images: torch.Tensor, attributes: dict | None = None):
+    def eval_losses(self, images: torch.Tensor, attributes: dict | None = None, adversarial: bool = False):
         """Validation forward as the reference does it (``validate``: SAMPLED forward under no_grad,
-        train_vae.py:555-560; AR-VAE term :573-589).  Returns device scalars {"recon", "kl"[, "ar", ...]} and the
-        reconstruction."""
+        train_vae.py:555-560; adversarial terms :564-571; AR-VAE term :573-589).  Returns device scalars {"recon",
+        "kl"[, "ar", ...][, "adv_gen", "adv_disc"]} and the reconstruction."""
         mu, sigma, _ = self.eng.encode_forward(images, save=False)
         eps = torch.randn(sigma.shape, generator=self.gen, device=sigma.device, dtype=sigma.dtype)
         recon, _ = self.eng.decode_forward(torch.addcmul(mu, eps, sigma), save=False)
@@ -233,4 +295,9 @@ class VAETrainer:
         res = {"recon": out2[0], "kl": out2[1]}
         if self.ar is not None:
             res["ar"], res["ar_per_attr"], res["ar_pairs"] = self._ar_term(mu, attributes, None)
+        if adversarial:
+            if self.disc is None:
+                raise ValueError("eval_losses(adversarial=True) needs VAETrainer(discriminator=...)")
+            adv_gen, ctx = self._adv_generator_term(recon, None)
+            res["adv_gen"], res["adv_disc"] = adv_gen[0], self._adv_discriminator_losses(ctx, images, train=False)[0]
         return res, recon
