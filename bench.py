@@ -253,6 +253,9 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--config", default=os.path.join(ROOT, "config", "vae_dente_no_adv.json"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--adv", action="store_true",
+                    help="time the step of epochs > 5 of an adv_enabled config: + PatchDiscriminator generator term and "
+                         "discriminator step (train_vae.py:399-401,447-458); needs a 1-channel model")
     ap.add_argument("--cpu-steps", type=int, default=10,
                     help="timed oracle steps of the cpu_baseline leg (batch 4: ~10 s of CPU work on 16 cores)")
     args = ap.parse_args()
@@ -278,7 +281,7 @@ def main():
     torch.cuda.set_device(dev)
 
     global PMC_WORKLOAD
-    PMC_WORKLOAD = f"{os.path.basename(args.config)}:b{args.batch}:{args.size}"
+    PMC_WORKLOAD = f"{os.path.basename(args.config)}:b{args.batch}:{args.size}" + (":adv" if args.adv else "")
     cfg = read_config(args.config)
     if "regressor_def" in cfg or "regression_train" in cfg:      # BASELINE config 5: regression on frozen latents
         return bench_regression(args, cfg, dev, world, rank, dist)
@@ -292,8 +295,14 @@ def main():
     from pti_ldm_vae_amd.utils import resolve_ar_settings
     ar_on, ar_gamma, _, _ = resolve_ar_settings(tr, cfg.get("regularized_attributes"))
     ar = ARSettings.from_config(cfg["regularized_attributes"], ar_gamma, cfg_def["latent_channels"]) if ar_on else None
+    disc = None
+    if args.adv:
+        from pti_ldm_vae_amd.models import PatchDiscriminator
+        disc = PatchDiscriminator(spatial_dims=2, num_layers_d=3, channels=32, in_channels=1, out_channels=1,
+                                  norm="INSTANCE").to(dev)
     trainer = VAETrainer(model, lr=tr["lr"], world_size=world, recon_loss=tr["recon_loss"], kl_weight=tr["kl_weight"],
-                         rank_eps_offset=rank, ar=ar)
+                         rank_eps_offset=rank, ar=ar, discriminator=disc, adv_weight=float(tr.get("adv_weight", 0.0)))
+    step_kw = {"adversarial": True} if args.adv else {}
     images = synthetic_batch(args.batch, cfg_def["in_channels"], args.size, dev, seed=42 + rank)
     attrs = None
     if ar is not None:
@@ -311,7 +320,7 @@ def main():
 
     log(f"model built, {sum(p.numel() for p in model.parameters())} params; warm-up {args.warmup} steps")
     for i in range(args.warmup):
-        trainer.step(images, attributes=attrs)
+        trainer.step(images, attributes=attrs, **step_kw)
         if i == 0:
             torch.cuda.synchronize()
             log("first step done")
@@ -323,7 +332,7 @@ def main():
     marks[0].record()
     for i in range(args.steps):
         h0 = time.perf_counter()
-        out = trainer.step(images, attributes=attrs)
+        out = trainer.step(images, attributes=attrs, **step_kw)
         host += time.perf_counter() - h0          # time the host spends enqueuing (incl. waiting on the 2-steps-in-flight cap)
         marks[i + 1].record()
     sync_all()
@@ -335,7 +344,7 @@ def main():
     cap, trainer.max_steps_in_flight = trainer.max_steps_in_flight, 1 << 20
     h0 = time.perf_counter()
     for _ in range(4):
-        trainer.step(images, attributes=attrs)
+        trainer.step(images, attributes=attrs, **step_kw)
     host_only = (time.perf_counter() - h0) / 4
     sync_all()
     trainer.max_steps_in_flight = cap
@@ -356,7 +365,7 @@ def main():
     side = trainer.eng.wgrad_stream
     trainer.eng.wgrad_stream = None
     for _ in range(2):          # EVERY rank steps (the step contains collectives); only rank 0 records
-        trainer.step(images, attributes=attrs)
+        trainer.step(images, attributes=attrs, **step_kw)
     torch.cuda.synchronize()
     trainer.eng.wgrad_stream = side
     if rank == 0:
@@ -378,8 +387,12 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"config/{os.path.basename(args.config)} {args.size}x{args.size}x{cfg_def['in_channels']} "
-                                   f"batch {args.batch}/GPU: fwd + L1 + 1e-3*KL{' + 0.5*AR-VAE(6 attributes)' if ar else ''} + bwd + all-reduce + Adam "
-                                   "(perceptual/adversarial terms omitted: unavailable offline / inactive before epoch 6)",
+                                   f"batch {args.batch}/GPU: fwd + L1 + 1e-3*KL{' + 0.5*AR-VAE(6 attributes)' if ar else ''}"
+                                   + (f" + {trainer.adv_weight}*LSGAN(PatchDiscriminator) + bwd + all-reduce + Adam, then the "
+                                      "discriminator step (fake + real pass, bwd, all-reduce, Adam) "
+                                      "(perceptual term omitted: unavailable offline)" if args.adv else
+                                      " + bwd + all-reduce + Adam (perceptual term omitted: unavailable offline; adversarial "
+                                      "branch inactive before epoch 6, --adv times it)"),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss, 5)},
             "model_tflops_per_gpu": round(per_gpu * gflop_img / 1e3, 1) if gflop_img else None,
             "frac_of_mfma_peak_end_to_end": round(per_gpu * gflop_img / 1e3 / PEAK_BF16_TFLOPS, 4) if gflop_img else None,

@@ -317,10 +317,12 @@ int pti_pd_col2im_image(const void* d_patches, float* d_img, int n, int h, int w
 /* InstanceNorm backward, second pass: dy = rstd * (g - sums[0]/hw - xhat * sums[1]/hw); sums float [n][c][2]; dy may be g. */
 int pti_pd_in_bwd_apply(const void* g, const void* y, const float* norm, const float* sums, void* dy, int n, int hw,
                         int c, pti_stream_t s);
-/* PatchAdversarialLoss(criterion="least_squares"): *loss_out = mean((LeakyReLU_slope(logit) - target)^2) over `count`
- * 16-bit logits (element m at logits[m*stride]; slope 0.05 = MONAI's default activation, 1 = none); when d_logits is
- * given, row m of bf16 [count][stride] = {grad_scale * d(sum of squares)/d logit_m / 2 ... i.e. grad_scale * (a - target) *
- * LeakyReLU'(logit), 0, ...}: pass grad_scale = weight * 2 / count for d(weight * loss).                               */
+/* PatchAdversarialLoss(criterion="least_squares"): loss_out[0] = mean((LeakyReLU_slope(logit) - target)^2) over `count`
+ * 16-bit logits (element m at logits[m*stride]; slope 0.05 = MONAI's default activation, 1 = none).  loss_out must hold
+ * 1 + pti_pd_lsgan_blocks(count) floats (block partials, summed in block order by a second launch).  When d_logits is
+ * given, row m of bf16 [count][stride] = {grad_scale * (a_m - target) * LeakyReLU'(logit_m), 0, ...}: pass
+ * grad_scale = weight * 2 / count for d(weight * loss)/d logits.                                                     */
+int pti_pd_lsgan_blocks(int count);
 int pti_pd_lsgan(const void* logits, int logits_f16, int stride, int count, float target, float slope,
                  float grad_scale, float* loss_out, void* d_logits, pti_stream_t s);
 

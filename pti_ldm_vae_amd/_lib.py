@@ -90,6 +90,7 @@ SIGNATURES = {
     "pti_pd_col2im": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "pti_pd_col2im_image": (_I, [_P, _P, _I, _I, _I, _F, _I, _P]),
     "pti_pd_in_bwd_apply": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "pti_pd_lsgan_blocks": (_I, [_I]),
     "pti_pd_lsgan": (_I, [_P, _I, _I, _I, _F, _F, _F, _P, _P, _P]),
     "pti_adam_step": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I, _F, _P]),
     "pti_preprocess_batch": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P]),

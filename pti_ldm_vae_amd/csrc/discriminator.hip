@@ -259,17 +259,19 @@ __global__ __launch_bounds__(256) void pd_in_bwd_apply_kernel(const bf16* __rest
 }
 
 // ---- PatchAdversarialLoss(least_squares): mean((lrelu_slope(logit) - target)^2) and its gradient -------------------
-// ONE workgroup (the logit map is [N][30][30]): fixed-order sum.  logits: 16-bit, element m at m * stride.
-__global__ __launch_bounds__(1024) void pd_lsgan_kernel(const void* __restrict__ logits, int f16, int stride, int M, float target,
-                                                        float slope, float gscale, float* __restrict__ loss_out,
-                                                        bf16* __restrict__ dY) {
-  __shared__ float red[1024];
+// logits: 16-bit, element m at m * stride.  One logit per thread; block partial sums go to loss_out[1 + block] (plain
+// stores) and a one-block second launch adds them in block order: fixed-order sum, no atomics.
+__global__ __launch_bounds__(256) void pd_lsgan_kernel(const void* __restrict__ logits, int f16, int stride, int M, float target,
+                                                       float slope, float gscale, float* __restrict__ loss_out,
+                                                       bf16* __restrict__ dY) {
+  __shared__ float red[256];
+  const int m = blockIdx.x * 256 + threadIdx.x;
   float acc = 0.f;
-  for (int m = threadIdx.x; m < M; m += 1024) {
+  if (m < M) {
     const uint16_t raw = ((const uint16_t*)logits)[(size_t)m * stride];
     const float v = f16 ? (float)__builtin_bit_cast(_Float16, raw) : __uint_as_float((uint32_t)raw << 16);
     const float e = (v > 0.f ? v : v * slope) - target;
-    acc += e * e;
+    acc = e * e;
     if (dY) {
       float d[8] = {gscale * e * (v > 0.f ? 1.f : slope), 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       u32x4* row = (u32x4*)(dY + (size_t)m * stride);
@@ -279,11 +281,24 @@ __global__ __launch_bounds__(1024) void pd_lsgan_kernel(const void* __restrict__
   }
   red[threadIdx.x] = acc;
   __syncthreads();
-  for (int o = 512; o > 0; o >>= 1) {
+  for (int o = 128; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) *loss_out = red[0] / (float)M;
+  if (threadIdx.x == 0) loss_out[1 + blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void pd_lsgan_finalize_kernel(float* __restrict__ loss_out, int blocks, int M) {
+  __shared__ float red[256];
+  float acc = 0.f;
+  for (int b = threadIdx.x; b < blocks; b += 256) acc += loss_out[1 + b];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss_out[0] = red[0] / (float)M;
 }
 
 int stream_blocks(long long items) {
@@ -378,12 +393,17 @@ extern "C" int pti_pd_in_bwd_apply(const void* g, const void* y, const float* no
   return PTI_OK;
 }
 
+extern "C" int pti_pd_lsgan_blocks(int count) { return count > 0 ? (count + 255) / 256 : 0; }
+
 extern "C" int pti_pd_lsgan(const void* logits, int logits_f16, int stride, int count, float target, float slope,
                             float grad_scale, float* loss_out, void* d_logits, pti_stream_t s) {
   if (!logits || !loss_out || count <= 0 || stride <= 0) PTI_FAIL(PTI_EINVAL, "pd_lsgan: bad arguments");
   if (d_logits && stride % 8) PTI_FAIL(PTI_EUNSUPPORTED, "pd_lsgan: gradient rows need a stride that is a multiple of 8");
-  PTI_LAUNCH(pd_lsgan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)s, logits, logits_f16, stride, count, target, slope,
+  const int blocks = pti_pd_lsgan_blocks(count);
+  PTI_LAUNCH(pd_lsgan_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, logits, logits_f16, stride, count, target, slope,
              grad_scale, loss_out, (bf16*)d_logits);
   PTI_CHECK_LAUNCH("pd_lsgan");
+  PTI_LAUNCH(pd_lsgan_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, loss_out, blocks, count);
+  PTI_CHECK_LAUNCH("pd_lsgan_finalize");
   return PTI_OK;
 }

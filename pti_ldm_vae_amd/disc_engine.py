@@ -109,10 +109,9 @@ class DiscEngine:
         """PatchAdversarialLoss("least_squares") of this pass's logits -> (loss [1] fp32 device tensor, unweighted;
         d(weight * loss)/d logits as padded bf16 rows or None)."""
         rows = self.logit_rows(ctx)
-        loss = torch.empty(1, dtype=F32, device=self.dev)
         d = torch.empty_like(rows, dtype=BF16) if want_grad else None
-        ops.pd_lsgan(rows, target=1.0 if target_is_real else 0.0, slope=slope, grad_scale=2.0 * weight / rows.shape[0],
-                     loss_out=loss, d_logits=d)
+        loss = ops.pd_lsgan(rows, target=1.0 if target_is_real else 0.0, slope=slope, grad_scale=2.0 * weight / rows.shape[0],
+                            d_logits=d)
         return loss, d
 
     # ---- backward --------------------------------------------------------------------------------------------------

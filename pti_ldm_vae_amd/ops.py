@@ -703,16 +703,17 @@ def pd_in_bwd_apply(g, y, norm, sums, dy=None):
     return dy
 
 
-def pd_lsgan(logits_rows, *, target, slope=0.05, grad_scale=0.0, loss_out, d_logits=None):
-    """logits_rows: 16-bit [M, stride] (the logit is column 0).  Writes mean((LeakyReLU_slope(l) - target)^2) to the
-    one-element fp32 ``loss_out``; ``d_logits`` (bf16, same shape) gets grad_scale * (a - target) * LeakyReLU'(l) in
-    column 0 and zeros elsewhere."""
+def pd_lsgan(logits_rows, *, target, slope=0.05, grad_scale=0.0, d_logits=None):
+    """logits_rows: 16-bit [M, stride] (the logit is column 0).  Returns the one-element fp32 device tensor
+    mean((LeakyReLU_slope(l) - target)^2); ``d_logits`` (bf16, same shape) gets grad_scale * (a - target) * LeakyReLU'(l)
+    in column 0 and zeros elsewhere."""
     _chk(logits_rows, ACT16, "logits", 2)
     m, stride = logits_rows.shape
     if d_logits is not None:
         _chk(d_logits, BF16, "d_logits", 2)
         if d_logits.shape != logits_rows.shape:
             raise ValueError("pd_lsgan: d_logits shape")
+    buf = torch.empty(1 + L.lib().pti_pd_lsgan_blocks(m), dtype=F32, device=logits_rows.device)
     L.check(L.lib().pti_pd_lsgan(_ptr(logits_rows), int(logits_rows.dtype == F16), stride, m, float(target), float(slope),
-                                 float(grad_scale), _ptr(loss_out), _ptr(d_logits), _stream()), "pti_pd_lsgan")
-    return loss_out
+                                 float(grad_scale), _ptr(buf), _ptr(d_logits), _stream()), "pti_pd_lsgan")
+    return buf[:1]
