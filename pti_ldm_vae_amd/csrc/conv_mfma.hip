@@ -928,6 +928,7 @@ int launch2_cfg(ConvArgs a, hipStream_t st) {
   if constexpr (KS == 3) {   // the activated-input side output is a separate instantiation (3x3 only)
     if (a.act_out) {
       if (fwd_silu) PTI_LAUNCH((conv_mfma2_kernel<KS, CK, CT, PXF, true, 1, FPRO>), grid, dim3(256), 0, st, a);
+      else if (a.w_f16) return 2;
       else PTI_LAUNCH((conv_mfma2_kernel<KS, CK, CT, PXF, true, 0, -1>), grid, dim3(256), 0, st, a);
       return 0;
     }
@@ -936,6 +937,11 @@ int launch2_cfg(ConvArgs a, hipStream_t st) {
   }
   if (fwd_silu) PTI_LAUNCH((conv_mfma2_kernel<KS, CK, CT, PXF, false, 1, FPRO>), grid, dim3(256), 0, st, a);
   else if (fwd_plain) PTI_LAUNCH((conv_mfma2_kernel<KS, CK, CT, PXF, false, 1, PTI_PRO_NONE>), grid, dim3(256), 0, st, a);
+  // fp16 operands with any other prologue (GroupNorm without SiLU: the encoder's conv_out on the padded latent tile):
+  // the fp16-operand kernel with the run-time prologue flag.  (It used to fall through to the run-time-FORMAT
+  // instantiation below, which multiplies bf16 operands -- with fp16-packed weights that is garbage.)
+  else if (fm == 1 && !a.gn_mode && !a.pool2) PTI_LAUNCH((conv_mfma2_kernel<KS, CK, CT, PXF, false, 1, -1>), grid, dim3(256), 0, st, a);
+  else if (a.w_f16) return 2;   // no fp16-operand kernel for this launch: refuse instead of mis-reading the weights
   else if (dgrad) PTI_LAUNCH((conv_mfma2_kernel<KS, CK, CT, PXF, false, 2, PTI_PRO_NONE>), grid, dim3(256), 0, st, a);
   else if (dgrad_gn) PTI_LAUNCH((conv_mfma2_kernel<KS, CK, CT, PXF, false, 3, PTI_PRO_NONE>), grid, dim3(256), 0, st, a);
   else PTI_LAUNCH((conv_mfma2_kernel<KS, CK, CT, PXF, false, 0, -1>), grid, dim3(256), 0, st, a);
@@ -1195,6 +1201,7 @@ static int conv2d_mfma_impl(const void* x, const void* w_packed, const float* bi
     ck = pick_ck2(d->cin, cout_tile);
     rc = d->ksize == 1 ? launch2<1>(a, ck, cout_tile, (hipStream_t)s) : launch2<3>(a, ck, cout_tile, (hipStream_t)s);
   }
+  if (rc == 2) PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: no fp16-operand kernel for this launch (w_f16 with this prologue / epilogue)");
   if (rc != 0) PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: no kernel for ck=%d cout_tile=%d", ck, cout_tile);
   PTI_CHECK_LAUNCH("conv2d_mfma");
   return PTI_OK;

@@ -283,12 +283,34 @@ class _DirectConv:
         self.w_tck = self.w_tck_t = None
         self.convs = []
         self.needs_in_stats = self.norm is not None
+        # The launch that PRODUCES the narrow side (conv_out forward: wide -> narrow; conv_in data gradient: wide ->
+        # narrow) is a reduction over the wide channels per output.  The direct kernel does it with VALU dot products
+        # reduced across lanes, which is fine for 1-4 narrow channels and collapses for 16 (AR config: 256 -> 16 at 64^2
+        # took 2.7 ms per launch, 25 % of the step).  For 5..32 narrow channels it goes to the MFMA conv instead, with
+        # the narrow channels zero-padded to one 32-wide MFMA tile (`wpad` = fp32 master copy with the padding, `wp_mfma`
+        # its packed operand; Engine.refresh_weights keeps both current) and the result sliced back.
+        narrow, wide = min(self.cin, self.cout), max(self.cin, self.cout)
+        self.mfma_narrow = 4 < narrow <= 32 and wide % 32 == 0
+        self.wpad = self.wp_mfma = None
+        self.pack_f16 = False
 
     def repack(self):
         w = self.w.data
         self.w_tck = w.permute(2, 3, 1, 0).reshape(9, self.cin, self.cout).contiguous()
         # data-gradient operand: w'[tap'][co][ci] = w[co][ci][8 - tap']
         self.w_tck_t = w.flip(2, 3).permute(2, 3, 0, 1).reshape(9, self.cout, self.cin).contiguous()
+        if self.mfma_narrow:
+            if self.wpad is None:   # narrow channels padded to 32: [32, wide, 3, 3] (conv_out) or [wide, 32, 3, 3] (conv_in)
+                shape = (32, self.cin, 3, 3) if self.cout < self.cin else (self.cout, 32, 3, 3)
+                self.wpad = torch.zeros(shape, dtype=F32, device=w.device)
+                self.bpad = torch.zeros(32, dtype=F32, device=w.device)
+            if self.cout < self.cin:    # forward operand of conv_out (fp16 when the forward pass runs fp16 operands)
+                self.wpad[:self.cout].copy_(w)
+                self.bpad[:self.cout].copy_(self.b.data)
+                self.wp_mfma = ops.pack_conv_weight(self.wpad, 3, PTI_CONV_S1, out=self.wp_mfma, f16=self.pack_f16)
+            else:                       # data-gradient operand of conv_in: W'[ci(pad 32)][co]
+                self.wpad[:, :self.cin].copy_(w)
+                self.wp_mfma = ops.pack_conv_weight(self.wpad, 3, PTI_CONV_S1, flip=True, out=self.wp_mfma)
 
 
 class _Plan:
@@ -365,6 +387,7 @@ class Engine:
         for c in self.mfma_convs:
             c.f16 = c.fwd_f16 and self.act_dtype == torch.float16
         self.direct_convs = [self.enc_in, self.enc_out, self.dec_in, self.dec_out]
+        self.enc_out.pack_f16 = self.act_dtype == torch.float16     # forward launch: fp16 operands like every forward conv
         self.Lc = net.latent_channels
         self._plist = list(net._param_by_name.values())
 
@@ -561,11 +584,17 @@ class Engine:
         saved = [] if save else None
         act = self._walk_fwd(self.enc_layers, a0, True, saved)
         hl, wl, L = act.t.shape[1], act.t.shape[2], self.Lc
-        hlat = _empty((n, hl * wl, L), x, F32)
         nm = self.enc_out.norm
-        ops.conv_direct(act.t, self.enc_out.w_tck, self.enc_out.b.data, hlat.view(n, hl, wl, L), n=n, h=hl, w=wl, cin=act.t.shape[3], cout=L,
-                        prologue=PTI_PRO_GN, in_stats=act.stats, gamma=nm.weight.data, beta=nm.bias.data, groups=self.G,
-                        eps=self.eps)
+        if self.enc_out.mfma_narrow:   # latent_channels in 5..32: MFMA conv on the zero-padded 32-channel tile
+            ypad = _empty((n, hl, wl, 32), x, self.act_dtype)
+            ops.conv_mfma(act.t, self.enc_out.wp_mfma, self.enc_out.bpad, ypad, cout=32, ksize=3, prologue=PTI_PRO_GN,
+                          in_stats=act.stats, gamma=nm.weight.data, beta=nm.bias.data, groups=self.G, eps=self.eps)
+            hlat = ypad.view(n, hl * wl, 32)[..., :L].float()
+        else:
+            hlat = _empty((n, hl * wl, L), x, F32)
+            ops.conv_direct(act.t, self.enc_out.w_tck, self.enc_out.b.data, hlat.view(n, hl, wl, L), n=n, h=hl, w=wl,
+                            cin=act.t.shape[3], cout=L, prologue=PTI_PRO_GN, in_stats=act.stats, gamma=nm.weight.data,
+                            beta=nm.bias.data, groups=self.G, eps=self.eps)
         mu = _empty((n, L, hl, wl), x, F32)
         sigma = _empty((n, L, hl, wl), x, F32)
         zq_unused = _empty((n, hl * wl, L), x, F32)
@@ -670,8 +699,13 @@ class Engine:
                          ksize=3, sgn=-1, narrow_layout="nhwc", dw_strides=(1, L * 9, 9),
                          dbias_wide=gv(di.prefix + ".bias"))
         self._ready("decoder.blocks.0.")
-        dzq = _empty((n, hl * wl, L), z, F32)
-        ops.conv_direct(dout, di.w_tck_t, None, dzq.view(n, hl, wl, L), n=n, h=hl, w=wl, cin=di.cout, cout=L)
+        if di.mfma_narrow:
+            dpad = _empty((n, hl, wl, 32), z)
+            ops.conv_mfma(dout, di.wp_mfma, None, dpad, cout=32, ksize=3)
+            dzq = dpad.view(n, hl * wl, 32)[..., :L].float()
+        else:
+            dzq = _empty((n, hl * wl, L), z, F32)
+            ops.conv_direct(dout, di.w_tck_t, None, dzq.view(n, hl, wl, L), n=n, h=hl, w=wl, cin=di.cout, cout=L)
         wp, _ = self._qp("post_quant_conv")
         dz = torch.empty_like(z) if want_dz else None
         ops.post_quant_bwd(dzq, z, wp, dz, gv("post_quant_conv.conv.weight"), gv("post_quant_conv.conv.bias"))

@@ -84,6 +84,9 @@ def test_conv_mfma_fp16_storage(dev, n, cin, cout, h, w, ks, mode, pro, res, ost
     (2, 32, 64, 16, 16, 1, "s1", 0, False, False),      # nin_shortcut
     (1, 64, 64, 16, 32, 3, "s2", 0, False, True),       # v1 kernel (stride 2)
     (2, 32, 32, 16, 16, 3, "s2", 0, False, False),
+    (1, 256, 32, 8, 16, 3, "s1", 1, False, False),      # GroupNorm without SiLU: encoder conv_out on the padded latent tile
+    (2, 128, 128, 8, 8, 3, "s1", 1, False, True),
+    (2, 64, 64, 8, 8, 1, "s1", 1, False, False),
 ])
 def test_conv_mfma_fp16_operands(dev, n, cin, cout, h, w, ks, mode, pro, res, ostats):
     """Forward convs of the default engine: fp16 storage AND fp16 MFMA operands (pti_conv_desc.w_f16, weights packed
@@ -115,7 +118,7 @@ def test_conv_mfma_fp16_operands(dev, n, cin, cout, h, w, ks, mode, pro, res, os
     y = torch.full((n, ho, wo, cout), float("nan"), dtype=H16, device=dev)
     st = ops.gn_stats(xd, groups) if pro else None
     ost = torch.zeros(n, 16, 2, dtype=torch.int64, device=dev) if ostats else None
-    act = torch.full((n, h, w, cin), float("nan"), dtype=B16, device=dev) if (pro and mode == "s1" and ks == 3) else None
+    act = torch.full((n, h, w, cin), float("nan"), dtype=B16, device=dev) if (pro == 2 and mode == "s1" and ks == 3) else None
     ops.conv_mfma(xd, wp, bias.to(dev), y, cout=cout, ksize=ks, mode=m, prologue=pro, in_stats=st,
                   gamma=gamma.to(dev) if pro else None, beta=beta.to(dev) if pro else None, groups=groups, eps=eps,
                   residual=_nhwc(rs).to(dev, H16) if res else None, out_stats=ost, out_groups=16, act_out=act)
