@@ -227,7 +227,10 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const bf16* __rest
                                                               const float* __restrict__ delta, bf16* __restrict__ dqkv,
                                                               int L, float c_log2, float scale) {
   using C = ACfg<D>;
-  constexpr bool REGQ = (D <= 128);   // Q / dO fragments live in registers: LDS only holds the streamed K/V tile
+  // Q / dO fragments live in registers: LDS only holds the streamed K/V tile.  (Head dim 256 used to keep them in LDS:
+  // 113 KB per 2-wave workgroup = ONE workgroup per CU, half the SIMDs idle; in registers -- 448 of the 512 per lane --
+  // it is 38 KB and two workgroups per CU: 838 -> 413 us at L=4096, batch 8.)
+  constexpr bool REGQ = true;
   __shared__ __attribute__((aligned(16))) unsigned char smem[((REGQ ? 0 : 2 * TB) + 2 * C::KT) * C::P];
   unsigned char* sQ = smem;
   unsigned char* sDO = sQ + (REGQ ? 0 : TB) * C::P;
@@ -317,7 +320,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkdv_kernel(const bf16* __re
                                                                 int L, float c_log2, float scale) {
   using C = ACfg<D>;
   constexpr int DBL = C::DB / DSPLIT;  // d blocks accumulated by this workgroup
-  constexpr bool REGK = (D <= 128);    // K / V fragments of the owned keys live in registers
+  constexpr bool REGK = true;    // K / V fragments of the owned keys live in registers (head dim 256 too: 1542 -> 815 us, see dq)
   __shared__ __attribute__((aligned(16))) unsigned char smem[((REGK ? 0 : 2 * TB) + 2 * C::KT) * C::P + 2 * C::KT * 4];
   unsigned char* sK = smem;
   unsigned char* sV = sK + (REGK ? 0 : TB) * C::P;
