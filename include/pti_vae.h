@@ -233,7 +233,7 @@ int pti_post_quant(const float* z_nchw, const float* wp, const float* bp, float*
                    int hw, int l, pti_stream_t s);
 /* backward of pti_post_quant: dz (NCHW, may be NULL), gwp/gbp +=.  workspace: float scratch of
  * PTI_POST_QUANT_BWD_WS_FLOATS(l) elements (per-workgroup partials, added up in a fixed order by a second
- * launch: no float atomics for l == 4, see pti_latent_head_bwd).                                 */
+ * launch: no float atomics, see pti_latent_head_bwd).                                             */
 #define PTI_POST_QUANT_BWD_MAX_BLOCKS 256
 #define PTI_POST_QUANT_BWD_WS_FLOATS(l) (PTI_POST_QUANT_BWD_MAX_BLOCKS * ((l) * (l) + (l)))
 int pti_post_quant_bwd(const float* dzq_nhwc, const float* z_nchw, const float* wp, float* dz_nchw,
@@ -241,8 +241,8 @@ int pti_post_quant_bwd(const float* dzq_nhwc, const float* z_nchw, const float* 
                        pti_stream_t s);
 /* backward of pti_latent_head_fwd: dh, and g* += the six 1x1-conv parameter gradients.  workspace: float scratch
  * of PTI_LATENT_BWD_WS_FLOATS(l) elements -- every workgroup stores its partial gradients there and a second
- * launch adds them up in a fixed order (no float atomics: bitwise reproducible for l == 4, the reference's
- * latent width; other widths still fold per-element partials with LDS atomics inside a workgroup).            */
+ * launch adds them up in a fixed order (no float atomics, bitwise reproducible: l == 4 -- the reference's latent
+ * width -- keeps its partials in registers, other widths sum 128-element chunks in element order through LDS).   */
 #define PTI_LATENT_BWD_MAX_BLOCKS 512
 #define PTI_LATENT_BWD_WS_FLOATS(l) (PTI_LATENT_BWD_MAX_BLOCKS * 3 * ((l) * (l) + (l)))
 int pti_latent_head_bwd(const float* h, const float* eps, const float* wm, const float* bm,

@@ -132,6 +132,56 @@ __global__ __launch_bounds__(256) void post_quant_bwd_kernel(const float* dzq, c
   }
 }
 
+// Generic latent width (L <= 16, e.g. the AR config's 16): chunks of 128 elements; phase 1 = the per-element arithmetic,
+// one element per thread (threads 0..127), operands of the parameter gradients parked in LDS; phase 2 = thread (i, j) of
+// the L x L grid owns gwp[i][j] and sums its 128 products IN ELEMENT ORDER (fixed order: bitwise reproducible; the first
+// version folded per-element partials with LDS float atomics -- 816 contended atomics per element at L = 16: 455 us
+// for a 2 MB map, and run-to-run rounding differences).
+constexpr int GCH = 128;
+__global__ __launch_bounds__(256) void post_quant_bwd_generic_kernel(const float* dzq, const float* z, const float* wp, float* dz,
+                                                                     float* part, int B, int HW, int L) {
+  extern __shared__ float sm[];   // s_g [GCH][L], s_z [GCH][L]
+  float* s_g = sm;
+  float* s_z = sm + GCH * L;
+  const int t = threadIdx.x, LL = L * L + L;
+  const int pi = t / L, pj = t - pi * L;
+  const bool pair = t < L * L;
+  float aw = 0.f, ab = 0.f;
+  const long long total = (long long)B * HW, nch = (total + GCH - 1) / GCH;
+  for (long long c = blockIdx.x; c < nch; c += gridDim.x) {
+    const long long e = c * GCH + t;
+    if (t < GCH) {
+      if (e < total) {
+        const int p = e % HW;
+        const int b = e / HW;
+        float g[MAXL];
+        for (int i = 0; i < L; ++i) {
+          g[i] = dzq[e * L + i];
+          s_g[t * L + i] = g[i];
+          s_z[t * L + i] = z[((size_t)b * L + i) * HW + p];
+        }
+        if (dz)
+          for (int j = 0; j < L; ++j) {
+            float v = 0.f;
+            for (int i = 0; i < L; ++i) v += wp[i * L + j] * g[i];
+            dz[((size_t)b * L + j) * HW + p] = v;
+          }
+      } else {
+        for (int i = 0; i < L; ++i) s_g[t * L + i] = s_z[t * L + i] = 0.f;
+      }
+    }
+    __syncthreads();
+    if (pair)
+      for (int k = 0; k < GCH; ++k) aw += s_g[k * L + pi] * s_z[k * L + pj];
+    if (t < L)
+      for (int k = 0; k < GCH; ++k) ab += s_g[k * L + t];
+    __syncthreads();
+  }
+  float* row = part + (size_t)blockIdx.x * LL;
+  if (pair) row[pi * L + pj] = aw;
+  if (t < L) row[L * L + t] = ab;
+}
+
 struct LatBwdArgs {
   const float* h; const float* eps;
   const float* wm; const float* bm; const float* wl; const float* bl; const float* wp; const float* bp;
@@ -247,6 +297,99 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(LatBwdArgs a) {
     float v = sm[i];
     if constexpr (LT > 0) v = (sm[i] + sm[NACC + i]) + (sm[2 * NACC + i] + sm[3 * NACC + i]);
     a.part[(size_t)blockIdx.x * 3 * LL + i] = v;
+  }
+}
+
+// Generic latent width: same two-phase scheme as post_quant_bwd_generic_kernel for the three L x L parameter gradients
+// (gwm = sum dm (x) h, gwl = sum dl (x) h, gwp = sum dzq (x) z) and their bias gradients.
+__global__ __launch_bounds__(256) void latent_bwd_generic_kernel(LatBwdArgs a) {
+  extern __shared__ float sm[];   // five [GCH][L] tables: dm, dl, h, dzq, z
+  const int L = a.L, LL = L * L + L;
+  float* s_dm = sm;
+  float* s_dl = sm + GCH * L;
+  float* s_hv = sm + 2 * GCH * L;
+  float* s_g = sm + 3 * GCH * L;
+  float* s_z = sm + 4 * GCH * L;
+  const int t = threadIdx.x;
+  const int pi = t / L, pj = t - pi * L;
+  const bool pair = t < L * L;
+  float awm = 0.f, awl = 0.f, awp = 0.f, abm = 0.f, abl = 0.f, abp = 0.f;
+  const long long total = (long long)a.B * a.HW, nch = (total + GCH - 1) / GCH;
+  for (long long c = blockIdx.x; c < nch; c += gridDim.x) {
+    const long long e = c * GCH + t;
+    if (t < GCH) {
+      if (e < total) {
+        const int p = e % a.HW;
+        const int b = e / a.HW;
+        float hv[MAXL], sg[MAXL], ep[MAXL], dzv[MAXL], dm[MAXL], dl[MAXL], gq[MAXL];
+        bool inr[MAXL];
+        for (int j = 0; j < L; ++j) hv[j] = a.h[e * L + j];
+        for (int i = 0; i < L; ++i) {
+          float m = a.bm[i], l = a.bl[i];
+          for (int j = 0; j < L; ++j) {
+            m += a.wm[i * L + j] * hv[j];
+            l += a.wl[i * L + j] * hv[j];
+          }
+          inr[i] = (l >= -30.f) && (l <= 20.f);   // torch.clamp passes the gradient on the closed range
+          l = fminf(fmaxf(l, -30.f), 20.f);
+          sg[i] = expf(0.5f * l);
+          const size_t o = ((size_t)b * L + i) * a.HW + p;
+          ep[i] = a.eps ? a.eps[o] : 0.f;
+          s_z[t * L + i] = m + ep[i] * sg[i];
+          gq[i] = a.dzq ? a.dzq[e * L + i] : 0.f;
+          s_g[t * L + i] = gq[i];
+          s_hv[t * L + i] = hv[i];
+        }
+        for (int j = 0; j < L; ++j) {
+          float v = 0.f;
+          for (int i = 0; i < L; ++i) v += a.wp[i * L + j] * gq[i];
+          dzv[j] = v;
+        }
+        for (int i = 0; i < L; ++i) {
+          const size_t o = ((size_t)b * L + i) * a.HW + p;
+          dm[i] = dzv[i] + (a.dmu ? a.dmu[o] : 0.f);
+          const float dsg = dzv[i] * ep[i] + (a.dsigma ? a.dsigma[o] : 0.f);
+          dl[i] = inr[i] ? dsg * sg[i] * 0.5f : 0.f;
+          s_dm[t * L + i] = dm[i];
+          s_dl[t * L + i] = dl[i];
+        }
+        for (int j = 0; j < L; ++j) {
+          float v = 0.f;
+          for (int i = 0; i < L; ++i) v += a.wm[i * L + j] * dm[i] + a.wl[i * L + j] * dl[i];
+          a.dh[e * L + j] = v;
+        }
+      } else {
+        for (int i = 0; i < L; ++i)
+          s_dm[t * L + i] = s_dl[t * L + i] = s_hv[t * L + i] = s_g[t * L + i] = s_z[t * L + i] = 0.f;
+      }
+    }
+    __syncthreads();
+    if (pair)
+      for (int k = 0; k < GCH; ++k) {
+        const float h_ = s_hv[k * L + pj];
+        awm += s_dm[k * L + pi] * h_;
+        awl += s_dl[k * L + pi] * h_;
+        awp += s_g[k * L + pi] * s_z[k * L + pj];
+      }
+    if (t < L)
+      for (int k = 0; k < GCH; ++k) {
+        abm += s_dm[k * L + t];
+        abl += s_dl[k * L + t];
+        abp += s_g[k * L + t];
+      }
+    __syncthreads();
+  }
+  // block partial row, laid out [wm | bm | wl | bl | wp | bp] like the specialised kernel's
+  float* row = a.part + (size_t)blockIdx.x * 3 * LL;
+  if (pair) {
+    row[pi * L + pj] = awm;
+    row[LL + pi * L + pj] = awl;
+    row[2 * LL + pi * L + pj] = awp;
+  }
+  if (t < L) {
+    row[L * L + t] = abm;
+    row[LL + L * L + t] = abl;
+    row[2 * LL + L * L + t] = abp;
   }
 }
 
@@ -476,8 +619,8 @@ extern "C" int pti_post_quant_bwd(const float* dzq_nhwc, const float* z_nchw, co
   if (l == 4)
     PTI_LAUNCH(post_quant_bwd_kernel<4>, dim3(nb), dim3(256), 4 * ll * sizeof(float), (hipStream_t)s, dzq_nhwc,
                        z_nchw, wp, dz_nchw, workspace, b, hw, l);
-  else   // other latent widths fold per-element partials with LDS float atomics inside a workgroup
-    PTI_LAUNCH(post_quant_bwd_kernel<0>, dim3(nb), dim3(256), ll * sizeof(float), (hipStream_t)s, dzq_nhwc, z_nchw,
+  else   // other latent widths: two-phase kernel, fixed summation order
+    PTI_LAUNCH(post_quant_bwd_generic_kernel, dim3(nb), dim3(256), 2 * GCH * l * sizeof(float), (hipStream_t)s, dzq_nhwc, z_nchw,
                        wp, dz_nchw, workspace, b, hw, l);
   PTI_CHECK_LAUNCH("post_quant_bwd");
   FinSegs sg{{gwp, gbp}, {l * l, l}, 2};
@@ -504,10 +647,10 @@ extern "C" int pti_latent_head_bwd(const float* h, const float* eps, const float
     PTI_LAUNCH(latent_bwd_kernel<4>, dim3((unsigned)nb), dim3(256), 4 * 3 * ll * sizeof(float), (hipStream_t)s, a);
   }
   else {
-    // other latent widths: the per-element partials go through LDS float atomics inside a block (rounding order
-    // may vary run to run there); the cross-block stage is the same fixed-order one
-    nb = nblocks((long long)b * hw, 256);
-    PTI_LAUNCH(latent_bwd_kernel<0>, dim3((unsigned)nb), dim3(256), 3 * ll * sizeof(float), (hipStream_t)s, a);
+    // other latent widths: two-phase kernel (one chunk of 128 elements per block and iteration), fixed summation order
+    nb = ((long long)b * hw + GCH - 1) / GCH;
+    nb = nb < 1 ? 1 : (nb > PTI_LATENT_BWD_MAX_BLOCKS ? PTI_LATENT_BWD_MAX_BLOCKS : nb);
+    PTI_LAUNCH(latent_bwd_generic_kernel, dim3((unsigned)nb), dim3(256), 5 * GCH * l * sizeof(float), (hipStream_t)s, a);
   }
   PTI_CHECK_LAUNCH("latent_head_bwd");
   FinSegs sg{{gwm, gbm, gwl, gbl, gwp, gbp}, {l * l, l, l * l, l, l * l, l}, 6};

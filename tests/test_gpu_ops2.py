@@ -111,7 +111,7 @@ def test_pool2x2_sum(dev):
     _report("pool2x2", y.float().cpu().permute(0, 3, 1, 2), F.avg_pool2d(x, 2) * 4)
 
 
-@pytest.mark.parametrize("b,l,hs", [(2, 4, 8), (1, 10, 8), (3, 4, 5)])
+@pytest.mark.parametrize("b,l,hs", [(2, 4, 8), (1, 10, 8), (3, 4, 5), (2, 16, 16), (1, 3, 13)])
 def test_latent_head(dev, b, l, hs):
     """encode tail + sampling + post_quant_conv, forward and backward, vs torch autograd."""
     from pti_ldm_vae_amd import ops

@@ -135,17 +135,23 @@ def test_train_script_checkpoints_and_resume(dev, tmp_path):
         train_vae.main(["-c", str(cf), "--synthetic", "8"])
 
 
-@pytest.mark.parametrize("batch,size", [(4, 128), (3, 72)])
-def test_training_steps_are_bitwise_reproducible(dev, batch, size):
+@pytest.mark.parametrize("batch,size,latent", [(4, 128, 4), (3, 72, 4), (3, 64, 16)])
+def test_training_steps_are_bitwise_reproducible(dev, batch, size, latent):
     """Same weights + same batch + same noise -> the SAME bits after three optimiser steps, run after run.  Holds
     because no floating-point atomics are left on the step's path: GroupNorm statistics are integer fixed-point sums,
     every other reduction (GroupNorm backward sums, weight-gradient splits, latent-head gradients, loss terms) stores
     per-workgroup partials and adds them up in a fixed order.  (The weight gradients run on the side stream here, so
-    this also covers the ordering between the two streams.)"""
+    this also covers the ordering between the two streams.)  latent = 16 is the AR config's width: the latent-head
+    kernels' generic path (fixed-order chunk sums) and the MFMA-routed latent convs."""
+    from pti_ldm_vae_amd.models import VAEModel
     from pti_ldm_vae_amd.trainer import VAETrainer
     torch.manual_seed(3)
     x = torch.randn(batch, 1, size, size, device=dev)
-    eps = torch.randn(3, batch, 4, size // 2, size // 2, device=dev)
+    eps = torch.randn(3, batch, latent, size // 2, size // 2, device=dev)
+
+    def _model(dev, seed=0):
+        torch.manual_seed(seed)
+        return VAEModel.from_config(dict(SMALL, latent_channels=latent)).to(dev)
     ref = _model(dev)
     state = {k: v.clone() for k, v in ref.state_dict().items()}
     runs = []
