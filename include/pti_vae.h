@@ -326,6 +326,23 @@ int pti_pd_lsgan_blocks(int count);
 int pti_pd_lsgan(const void* logits, int logits_f16, int stride, int count, float target, float slope,
                  float grad_scale, float* loss_out, void* d_logits, pti_stream_t s);
 
+/* Final block of the discriminator (C -> 1 channel, 4x4, stride 1, pad 1) WITHOUT a patch matrix: with one output
+ * channel the lowering above would move ~15x the bytes of its input.  The activated input LeakyReLU(norm(y_prev)) is
+ * rebuilt on the fly; logits and d_logits are fp32 [n][h-1][w-1]; w is fp32 [16][c] (tap-major), bias fp32 [1].
+ *   fwd:   logits = conv(act(norm(y_prev)), w) + bias
+ *   dgrad: g = act'(xhat) * conv^T(d_logits, w)  (bf16 [n][h][w][c]) + InstanceNorm-backward partials as pti_pd_col2im
+ *          (same pti_pd_col2im_blocks(n, h*w, c) rows)
+ *   wgrad: partials float [pti_pd_final_wgrad_blocks(n,h,w)][16*c + 8] = per-block {dw[16][c], dbias, 0..}; sum the rows
+ *          in block order (pti_gn_sums_finalize(partials, out, 1, blocks, 16*c + 8)).
+ * pti_pd_lsgan accepts such fp32 logits with logits_f16 = 2 (stride in floats, d_logits then is float[count*stride]). */
+int pti_pd_final_fwd(const void* y_prev, const float* norm, const float* w, const float* bias, float* logits, int n,
+                     int h, int w_, int c, float slope, pti_stream_t s);
+int pti_pd_final_dgrad(const float* d_logits, const void* y_prev, const float* norm, const float* w, void* g,
+                       float* partials, int n, int h, int w_, int c, float slope, pti_stream_t s);
+int pti_pd_final_wgrad_blocks(int n, int h, int w_);
+int pti_pd_final_wgrad(const float* d_logits, const void* y_prev, const float* norm, float* partials, int n, int h,
+                       int w_, int c, float slope, pti_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -92,6 +92,10 @@ SIGNATURES = {
     "pti_pd_in_bwd_apply": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "pti_pd_lsgan_blocks": (_I, [_I]),
     "pti_pd_lsgan": (_I, [_P, _I, _I, _I, _F, _F, _F, _P, _P, _P]),
+    "pti_pd_final_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "pti_pd_final_dgrad": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "pti_pd_final_wgrad_blocks": (_I, [_I, _I, _I]),
+    "pti_pd_final_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "pti_adam_step": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I, _F, _P]),
     "pti_preprocess_batch": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "pti_cast_nchw_f32_to_nhwc_bf16": (_I, [_P, _P, _I, _I, _I, _P]),

@@ -258,6 +258,202 @@ __global__ __launch_bounds__(256) void pd_in_bwd_apply_kernel(const bf16* __rest
   }
 }
 
+// ---- final block (C -> 1 channel, 4x4, stride 1, pad 1) without the patch matrix -----------------------------------
+// The last convolution has ONE output channel: lowered like the others it would write, read, and read again a
+// [n][ho][wo][16*C] patch matrix (236 MB at batch 32) plus its gradient for 7 MFLOP per image.  Direct kernels
+// instead: the activated input LeakyReLU(InstanceNorm(y_prev)) is rebuilt on the fly from y_prev (16 MB) wherever it is
+// needed; logits and their gradient are fp32 [n][ho][wo].  w: fp32 [16][C] (tap-major), C = 32..256.
+struct FinalArgs {
+  const bf16* yprev;     // [N][H][W][C]
+  const float* norm;     // [N][C][2] or null
+  const float* w;        // [16][C]
+  const float* bias;     // [1]
+  float* logits;         // [N][Ho][Wo]            (forward)
+  const float* dlogits;  // [N][Ho][Wo]            (backward)
+  bf16* g;               // [N][H][W][C]           (data gradient, LeakyReLU' applied)
+  float* part;           // data gradient: [N][bps][C][2] InstanceNorm-backward partials; weight gradient: [blocks][16*C + 8]
+  int N, H, W, C, Ho, Wo, ppb, bps;
+  float slope;
+};
+
+// forward: 256 threads = (256 / NC) output pixels x NC channel octets; the C-long dot products are folded over the NC
+// lanes of a pixel with a fixed shuffle tree.
+__global__ __launch_bounds__(256) void pd_final_fwd_kernel(FinalArgs a) {
+  extern __shared__ float wsm[];   // [16][C]
+  const int NC = a.C >> 3, ppi = 256 / NC, tid = threadIdx.x, lc = tid % NC, lp = tid / NC;
+  for (int i = tid; i < 16 * a.C; i += 256) wsm[i] = a.w[i];
+  __syncthreads();
+  const int total = a.N * a.Ho * a.Wo;
+  const float b0 = a.bias[0];
+  for (int m0 = blockIdx.x * ppi; m0 < total; m0 += gridDim.x * ppi) {
+    const int m = m0 + lp;
+    float acc = 0.f;
+    if (m < total) {
+      const int ox = m % a.Wo, t = m / a.Wo, oy = t % a.Ho, n = t / a.Ho;
+      float mean[8], rstd[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { mean[j] = 0.f; rstd[j] = 1.f; }
+      if (a.norm) {
+        const float* nt = a.norm + ((size_t)n * a.C + lc * 8) * 2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { mean[j] = nt[2 * j]; rstd[j] = nt[2 * j + 1]; }
+      }
+#pragma unroll
+      for (int tap = 0; tap < 16; ++tap) {
+        const int iy = oy - 1 + (tap >> 2), ix = ox - 1 + (tap & 3);
+        if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) {
+          float f[8];
+          unpack8(*(const u32x4*)(a.yprev + (((size_t)n * a.H + iy) * a.W + ix) * a.C + lc * 8), f);
+          const float* wr = wsm + tap * a.C + lc * 8;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float v = (f[j] - mean[j]) * rstd[j];
+            v = v > 0.f ? v : v * a.slope;
+            acc += v * wr[j];
+          }
+        }
+      }
+    }
+    for (int o = 1; o < NC; o <<= 1) acc += __shfl_xor(acc, o, 64);
+    if (m < total && lc == 0) a.logits[m] = acc + b0;
+  }
+}
+
+// data gradient w.r.t. the activated input, times LeakyReLU', + InstanceNorm-backward block partials (as pd_col2im)
+__global__ __launch_bounds__(256) void pd_final_dgrad_kernel(FinalArgs a) {
+  extern __shared__ float sm[];    // [16][C] weights, then [ppi][NC][16] reduction scratch
+  float* wsm = sm;
+  float* red = sm + 16 * a.C;
+  const int n = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
+  const int NC = a.C >> 3, ppi = 256 / NC, lc = tid % NC, lp = tid / NC;
+  const int HW = a.H * a.W;
+  for (int i = tid; i < 16 * a.C; i += 256) wsm[i] = a.w[i];
+  float mean[8], rstd[8], s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = s2[j] = 0.f; mean[j] = 0.f; rstd[j] = 1.f; }
+  if (a.norm) {
+    const float* nt = a.norm + ((size_t)n * a.C + lc * 8) * 2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { mean[j] = nt[2 * j]; rstd[j] = nt[2 * j + 1]; }
+  }
+  __syncthreads();
+  const int p_end = min(HW, (blk + 1) * a.ppb);
+  for (int p = blk * a.ppb + lp; p < p_end; p += ppi) {
+    const int y = p / a.W, x = p - y * a.W;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 16; ++tap) {
+      const int oy = y + 1 - (tap >> 2), ox = x + 1 - (tap & 3);
+      if ((unsigned)oy < (unsigned)a.Ho && (unsigned)ox < (unsigned)a.Wo) {
+        const float d = a.dlogits[((size_t)n * a.Ho + oy) * a.Wo + ox];
+        const float* wr = wsm + tap * a.C + lc * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += d * wr[j];
+      }
+    }
+    float v[8];
+    const size_t off = ((size_t)n * HW + p) * a.C + lc * 8;
+    unpack8(*(const u32x4*)(a.yprev + off), v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xh = (v[j] - mean[j]) * rstd[j];
+      const float gj = acc[j] * (xh > 0.f ? 1.f : a.slope);
+      acc[j] = gj;
+      s1[j] += gj;
+      s2[j] += gj * xh;
+    }
+    *(u32x4*)(a.g + off) = pack8(acc);
+  }
+  if (!a.part) return;
+  float* slot = red + (lp * NC + lc) * 16;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { slot[j] = s1[j]; slot[8 + j] = s2[j]; }
+  __syncthreads();
+  for (int o = ppi >> 1; o > 0; o >>= 1) {
+    if (lp < o) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) slot[j] += slot[o * NC * 16 + j];
+    }
+    __syncthreads();
+  }
+  if (lp == 0) {
+    float* row = a.part + (((size_t)n * a.bps + blk) * a.C + lc * 8) * 2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { row[2 * j] = slot[j]; row[2 * j + 1] = slot[8 + j]; }
+  }
+}
+
+// weight gradient, input-pixel centric: dw[tap][c] = sum over INPUT pixels q of act(q)[c] * d_logits[q + (1,1) - tap], so
+// every activated pixel is loaded and normalised ONCE and feeds 16 tap accumulators (the output-centric form re-read
+// each pixel 16 times through a serial, latency-bound loop: 174 us at batch 32).  A block owns FW_PIX consecutive
+// input pixels of the flattened [n*h*w] range; thread = (channel octet lc, pixel lane lp), 16 x 8 accumulators; the
+// pixel lanes are folded through LDS in a fixed order and the block's partial row [16][C] (+ bias sum) is stored.
+constexpr int FW_PIX = 256;
+__global__ __launch_bounds__(256) void pd_final_wgrad_kernel(FinalArgs a) {
+  extern __shared__ float red[];   // [ppi][16][C] would be too large: folded tap by tap -> [ppi][C] per tap
+  const int NC = a.C >> 3, ppi = 256 / NC, tid = threadIdx.x, lc = tid % NC, lp = tid / NC;
+  const int HW = a.H * a.W, total = a.N * HW;
+  const int q0 = blockIdx.x * FW_PIX, q1 = min(total, q0 + FW_PIX);
+  float acc[16][8];
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+  for (int q = q0 + lp; q < q1; q += ppi) {
+    const int n = q / HW, p = q - n * HW, y = p / a.W, x = p - y * a.W;
+    float f[8];
+    unpack8(*(const u32x4*)(a.yprev + (size_t)q * a.C + lc * 8), f);
+    if (a.norm) {
+      const float* nt = a.norm + ((size_t)n * a.C + lc * 8) * 2;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = (f[j] - nt[2 * j]) * nt[2 * j + 1];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = f[j] > 0.f ? f[j] : f[j] * a.slope;
+    const float* dn = a.dlogits + (size_t)n * a.Ho * a.Wo;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int oy = y + 1 - (t >> 2), ox = x + 1 - (t & 3);
+      const float d = ((unsigned)oy < (unsigned)a.Ho && (unsigned)ox < (unsigned)a.Wo) ? dn[oy * a.Wo + ox] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[t][j] += d * f[j];
+    }
+  }
+  float* row = a.part + (size_t)blockIdx.x * (16 * a.C + 8);
+  for (int t = 0; t < 16; ++t) {   // fold the pixel lanes, one tap at a time (LDS: ppi * C floats = 8 KiB)
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[lp * a.C + lc * 8 + j] = acc[t][j];
+    __syncthreads();
+    for (int o = ppi >> 1; o > 0; o >>= 1) {
+      if (lp < o) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[lp * a.C + lc * 8 + j] += red[(lp + o) * a.C + lc * 8 + j];
+      }
+      __syncthreads();
+    }
+    if (lp == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) row[t * a.C + lc * 8 + j] = red[lc * 8 + j];
+    }
+  }
+  // bias gradient = sum of d_logits: block b sums the slice [b * chunk, (b+1) * chunk) of the logit map, fixed tree
+  __syncthreads();
+  const int M = a.N * a.Ho * a.Wo, chunk = (M + gridDim.x - 1) / gridDim.x;
+  float bs = 0.f;
+  for (int m = blockIdx.x * chunk + tid; m < min(M, (int)(blockIdx.x + 1) * chunk); m += 256) bs += a.dlogits[m];
+  red[tid] = bs;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) row[16 * a.C] = red[0];
+  if (tid > 0 && tid < 8) row[16 * a.C + tid] = 0.f;
+}
+
 // ---- PatchAdversarialLoss(least_squares): mean((lrelu_slope(logit) - target)^2) and its gradient -------------------
 // logits: 16-bit, element m at m * stride.  One logit per thread; block partial sums go to loss_out[1 + block] (plain
 // stores) and a one-block second launch adds them in block order: fixed-order sum, no atomics.
@@ -268,11 +464,18 @@ __global__ __launch_bounds__(256) void pd_lsgan_kernel(const void* __restrict__ 
   const int m = blockIdx.x * 256 + threadIdx.x;
   float acc = 0.f;
   if (m < M) {
-    const uint16_t raw = ((const uint16_t*)logits)[(size_t)m * stride];
-    const float v = f16 ? (float)__builtin_bit_cast(_Float16, raw) : __uint_as_float((uint32_t)raw << 16);
+    float v;
+    if (f16 == 2) {
+      v = ((const float*)logits)[(size_t)m * stride];
+    } else {
+      const uint16_t raw = ((const uint16_t*)logits)[(size_t)m * stride];
+      v = f16 ? (float)__builtin_bit_cast(_Float16, raw) : __uint_as_float((uint32_t)raw << 16);
+    }
     const float e = (v > 0.f ? v : v * slope) - target;
     acc = e * e;
-    if (dY) {
+    if (dY && f16 == 2) {
+      ((float*)dY)[(size_t)m * stride] = gscale * e * (v > 0.f ? 1.f : slope);
+    } else if (dY) {
       float d[8] = {gscale * e * (v > 0.f ? 1.f : slope), 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       u32x4* row = (u32x4*)(dY + (size_t)m * stride);
       row[0] = pack8(d);
@@ -398,12 +601,65 @@ extern "C" int pti_pd_lsgan_blocks(int count) { return count > 0 ? (count + 255)
 extern "C" int pti_pd_lsgan(const void* logits, int logits_f16, int stride, int count, float target, float slope,
                             float grad_scale, float* loss_out, void* d_logits, pti_stream_t s) {
   if (!logits || !loss_out || count <= 0 || stride <= 0) PTI_FAIL(PTI_EINVAL, "pd_lsgan: bad arguments");
-  if (d_logits && stride % 8) PTI_FAIL(PTI_EUNSUPPORTED, "pd_lsgan: gradient rows need a stride that is a multiple of 8");
+  if (logits_f16 < 0 || logits_f16 > 2) PTI_FAIL(PTI_EINVAL, "pd_lsgan: logits format %d", logits_f16);
+  if (d_logits && logits_f16 != 2 && stride % 8) PTI_FAIL(PTI_EUNSUPPORTED, "pd_lsgan: gradient rows need a stride that is a multiple of 8");
   const int blocks = pti_pd_lsgan_blocks(count);
   PTI_LAUNCH(pd_lsgan_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, logits, logits_f16, stride, count, target, slope,
              grad_scale, loss_out, (bf16*)d_logits);
   PTI_CHECK_LAUNCH("pd_lsgan");
   PTI_LAUNCH(pd_lsgan_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, loss_out, blocks, count);
   PTI_CHECK_LAUNCH("pd_lsgan_finalize");
+  return PTI_OK;
+}
+
+// ---- final block, direct (see pd_final_*_kernel) ----------------------------------------------------------------------
+static int final_args(FinalArgs& a, const void* y_prev, const float* norm, const float* w, int n, int h, int w_, int c, float slope) {
+  if (!y_prev || !w || n <= 0 || h < 3 || w_ < 3) PTI_FAIL(PTI_EINVAL, "pd_final: bad arguments");
+  if (!pd_channels_ok(c)) PTI_FAIL(PTI_EUNSUPPORTED, "pd_final: c=%d", c);
+  a = FinalArgs{};
+  a.yprev = (const bf16*)y_prev; a.norm = norm; a.w = w;
+  a.N = n; a.H = h; a.W = w_; a.C = c; a.Ho = h - 1; a.Wo = w_ - 1; a.slope = slope;
+  return PTI_OK;
+}
+
+extern "C" int pti_pd_final_fwd(const void* y_prev, const float* norm, const float* w, const float* bias, float* logits, int n,
+                                int h, int w_, int c, float slope, pti_stream_t s) {
+  FinalArgs a;
+  if (int rc = final_args(a, y_prev, norm, w, n, h, w_, c, slope)) return rc;
+  if (!bias || !logits) PTI_FAIL(PTI_EINVAL, "pd_final_fwd: null pointer");
+  a.bias = bias; a.logits = logits;
+  const int ppi = 256 / (c / 8);
+  int blocks = (n * a.Ho * a.Wo + ppi - 1) / ppi;
+  if (blocks > 768) blocks = 768;   // persistent blocks: the 16*c weight table is staged into LDS once per block
+  PTI_LAUNCH(pd_final_fwd_kernel, dim3(blocks), dim3(256), 16 * c * sizeof(float), (hipStream_t)s, a);
+  PTI_CHECK_LAUNCH("pd_final_fwd");
+  return PTI_OK;
+}
+
+extern "C" int pti_pd_final_dgrad(const float* d_logits, const void* y_prev, const float* norm, const float* w, void* g,
+                                  float* partials, int n, int h, int w_, int c, float slope, pti_stream_t s) {
+  FinalArgs a;
+  if (int rc = final_args(a, y_prev, norm, w, n, h, w_, c, slope)) return rc;
+  if (!d_logits || !g) PTI_FAIL(PTI_EINVAL, "pd_final_dgrad: null pointer");
+  if ((norm != nullptr) != (partials != nullptr)) PTI_FAIL(PTI_EINVAL, "pd_final_dgrad: norm and partials go together");
+  a.dlogits = d_logits; a.g = (bf16*)g; a.part = partials;
+  col2im_plan(n, h * w_, c, a.ppb, a.bps);
+  PTI_LAUNCH(pd_final_dgrad_kernel, dim3(a.bps, n), dim3(256), (16 * c + 256 * 16) * sizeof(float), (hipStream_t)s, a);
+  PTI_CHECK_LAUNCH("pd_final_dgrad");
+  return PTI_OK;
+}
+
+extern "C" int pti_pd_final_wgrad_blocks(int n, int h, int w_) { return n > 0 && h > 1 && w_ > 1 ? (n * h * w_ + FW_PIX - 1) / FW_PIX : 0; }
+
+extern "C" int pti_pd_final_wgrad(const float* d_logits, const void* y_prev, const float* norm, float* partials, int n, int h,
+                                  int w_, int c, float slope, pti_stream_t s) {
+  FinalArgs a;
+  const float dummy = 0.f;
+  if (int rc = final_args(a, y_prev, norm, &dummy, n, h, w_, c, slope)) return rc;
+  if (!d_logits || !partials) PTI_FAIL(PTI_EINVAL, "pd_final_wgrad: null pointer");
+  a.w = nullptr; a.dlogits = d_logits; a.part = partials;
+  PTI_LAUNCH(pd_final_wgrad_kernel, dim3(pti_pd_final_wgrad_blocks(n, h, w_)), dim3(256), (256 / (c / 8)) * c * sizeof(float),
+             (hipStream_t)s, a);
+  PTI_CHECK_LAUNCH("pd_final_wgrad");
   return PTI_OK;
 }

@@ -3,9 +3,10 @@ of the five 4x4 convolution blocks of MONAI's PatchDiscriminator(norm="INSTANCE"
 adversarial branch of its training step (``vae_scripts/train_vae.py:399-401`` generator term, ``:447-458``
 discriminator step, ``:564-571`` validation).
 
-Every block is  patches = im2col(LeakyReLU(InstanceNorm(previous conv output)))  ->  1x1 convolution on the MFMA
-kernel  (``ops.conv_mfma`` ksize 1): the pre-normalisation conv outputs ``y`` and the patch matrices ``P`` are what is
-kept for backward.  Backward per block: weight gradient = 1x1 weight gradient of (P, dy) (``ops.conv_wgrad_mfma``),
+Every block but the last is  patches = im2col(LeakyReLU(InstanceNorm(previous conv output)))  ->  1x1 convolution on the
+MFMA kernel  (``ops.conv_mfma`` ksize 1): the pre-normalisation conv outputs ``y`` and the patch matrices ``P`` are what
+is kept for backward.  The last block has ONE output channel -- a patch matrix would move ~15x the bytes of its input --
+and runs on direct kernels (``ops.pd_final_*``) with fp32 logits.  Backward per block: weight gradient = 1x1 weight gradient of (P, dy) (``ops.conv_wgrad_mfma``),
 data gradient = 1x1 conv with the transposed weight -> ``pd_col2im`` (gather + LeakyReLU' + InstanceNorm-backward sums)
 -> ``pd_in_bwd_apply``.  All on the caller's current stream; no host synchronisation; no float atomics.
 """
@@ -20,8 +21,8 @@ LRELU, IN_EPS = 0.2, 1e-5
 
 
 class DiscCtx:
-    """What one forward pass keeps: patches P[l], conv outputs y[l] (pre-norm), norm tables t[l] (None where the block
-    has no InstanceNorm), and the padded logit rows."""
+    """What one forward pass keeps: patches P[l] (None for the direct final block), conv outputs y[l] (pre-norm; the
+    last one = fp32 logits [B,Ho,Wo]), norm tables t[l] (None where the block has no InstanceNorm)."""
     __slots__ = ("P", "y", "t", "shape")
 
     def __init__(self):
@@ -42,6 +43,10 @@ class DiscEngine:
     def _w(self, lay, arena):
         return arena[lay["w_off"]:lay["w_off"] + lay["rows"] * lay["k"]].view(lay["rows"], lay["k"], 1, 1)
 
+    def _w16c(self, lay, arena):
+        """[16][cin] fp32 weight of the one-output-channel final block (row 0 of its padded arena slot)."""
+        return arena[lay["w_off"]:lay["w_off"] + lay["k"]]
+
     def _b(self, lay, arena):
         return None if lay["b_off"] is None else arena[lay["b_off"]:lay["b_off"] + lay["rows"]]
 
@@ -52,11 +57,13 @@ class DiscEngine:
         if self._packer is None:
             entries = []
             for lay in self.layers:
+                if lay["cout"] == 1:
+                    continue          # direct final block: reads the fp32 master weights
                 w = self._w(lay, self.net.param_arena)
                 entries += [(w, 1, ops.PTI_CONV_S1, False, False), (w, 1, ops.PTI_CONV_S1, True, False)]
             self._packer = ops.BatchedPacker(entries, self.dev)
-            self.wp = self._packer.outputs[0::2]
-            self.wpt = self._packer.outputs[1::2]
+            self.wp = self._packer.outputs[0::2] + [None]
+            self.wpt = self._packer.outputs[1::2] + [None]
         self._packer.run()
         self.packed_version = v
 
@@ -76,6 +83,15 @@ class DiscEngine:
         arena = self.net.param_arena
         prev, prev_t = None, None
         for i, lay in enumerate(self.layers):
+            if lay["cout"] == 1:      # final block: direct, fp32 logits
+                logits = torch.empty(b, prev.shape[1] - 1, prev.shape[2] - 1, dtype=F32, device=self.dev)
+                if logits.shape[1] < 1 or logits.shape[2] < 1:
+                    raise ValueError(f"PatchDiscriminator: input {h}x{w} is too small for {len(self.layers)} blocks")
+                ops.pd_final_fwd(prev, prev_t, self._w16c(lay, arena), self._b(lay, arena), logits, slope=LRELU)
+                ctx.P.append(None)
+                ctx.y.append(logits)
+                ctx.t.append(None)
+                break
             if i == 0:
                 P = torch.empty(b, h // 2, w // 2, 32, dtype=BF16, device=self.dev)
                 ops.pd_im2col_image(x, P)
@@ -97,19 +113,17 @@ class DiscEngine:
 
     @staticmethod
     def logit_rows(ctx: DiscCtx) -> torch.Tensor:
-        y = ctx.y[-1]
-        return y.view(-1, y.shape[3])
+        return ctx.y[-1].view(-1, 1)
 
     def logits(self, ctx: DiscCtx) -> torch.Tensor:
         """fp32 [B,1,Ho,Wo] like the reference's ``discriminator(x)[-1]``."""
-        y = ctx.y[-1]
-        return y[..., 0].float().unsqueeze(1).contiguous()
+        return ctx.y[-1].unsqueeze(1)
 
     def lsgan(self, ctx: DiscCtx, *, target_is_real: bool, weight: float = 1.0, want_grad: bool = True, slope: float = 0.05):
         """PatchAdversarialLoss("least_squares") of this pass's logits -> (loss [1] fp32 device tensor, unweighted;
-        d(weight * loss)/d logits as padded bf16 rows or None)."""
+        d(weight * loss)/d logits as fp32 [M,1] or None)."""
         rows = self.logit_rows(ctx)
-        d = torch.empty_like(rows, dtype=BF16) if want_grad else None
+        d = torch.empty_like(rows) if want_grad else None
         loss = ops.pd_lsgan(rows, target=1.0 if target_is_real else 0.0, slope=slope, grad_scale=2.0 * weight / rows.shape[0],
                             d_logits=d)
         return loss, d
@@ -117,13 +131,26 @@ class DiscEngine:
     # ---- backward --------------------------------------------------------------------------------------------------
     def backward(self, ctx: DiscCtx, d_rows: torch.Tensor, *, want_wgrad: bool, d_img: torch.Tensor | None = None,
                  dx_scale: float = 1.0, accumulate_dx: bool = False):
-        """d_rows: bf16 [B*Ho*Wo, 32] gradient w.r.t. the padded logit rows.  ``want_wgrad``: accumulate (+=) the
+        """d_rows: fp32 [B*Ho*Wo, 1] gradient w.r.t. the logits.  ``want_wgrad``: accumulate (+=) the
         parameter gradients into ``net.grad_arena``.  ``d_img`` (fp32 [B,1,H,W]): receives dx_scale * gradient w.r.t. the
         input image (added to its contents when ``accumulate_dx``)."""
         garena = self.net.grad_arena
-        dy = d_rows.view(ctx.y[-1].shape)
+        dy = None
         for i in range(len(self.layers) - 1, -1, -1):
             lay, P = self.layers[i], ctx.P[i]
+            if lay["cout"] == 1:      # direct final block
+                yp, tp = ctx.y[i - 1], ctx.t[i - 1]
+                if yp is None:
+                    raise RuntimeError("PatchDiscriminator.backward: the forward pass was run with save=False")
+                dl = d_rows.reshape(-1).float().contiguous()
+                if want_wgrad:
+                    gw = ops.pd_final_wgrad(dl, yp, tp, slope=LRELU)
+                    self._w16c(lay, garena).add_(gw[:lay["k"]])
+                    self._b(lay, garena)[:1].add_(gw[lay["k"]:lay["k"] + 1])
+                g = torch.empty_like(yp)
+                g, sums = ops.pd_final_dgrad(dl, yp, tp, self._w16c(lay, self.net.param_arena), g, slope=LRELU)
+                dy = ops.pd_in_bwd_apply(g, yp, tp, sums) if tp is not None else g
+                continue
             if P is None:
                 raise RuntimeError("PatchDiscriminator.backward: the forward pass was run with save=False")
             if want_wgrad:
@@ -176,8 +203,7 @@ class _DiscFn(torch.autograd.Function):
         eng, c = ctx.eng, ctx.c
         net = eng.net
         rows = eng.logit_rows(c)
-        d = torch.zeros(rows.shape, dtype=BF16, device=rows.device)
-        d[:, 0] = dlogits.reshape(-1).to(BF16)
+        d = dlogits.reshape(-1, 1).float().contiguous()
         names = list(net._param_by_name)
         need_w = any(ctx.needs_input_grad[2:])
         aliased = all(p.grad is not None and p.grad.data_ptr() == net.grad_view(n).data_ptr()

@@ -704,16 +704,67 @@ def pd_in_bwd_apply(g, y, norm, sums, dy=None):
 
 
 def pd_lsgan(logits_rows, *, target, slope=0.05, grad_scale=0.0, d_logits=None):
-    """logits_rows: 16-bit [M, stride] (the logit is column 0).  Returns the one-element fp32 device tensor
-    mean((LeakyReLU_slope(l) - target)^2); ``d_logits`` (bf16, same shape) gets grad_scale * (a - target) * LeakyReLU'(l)
-    in column 0 and zeros elsewhere."""
-    _chk(logits_rows, ACT16, "logits", 2)
+    """logits_rows: [M, stride], the logit in column 0 -- 16-bit padded rows, or fp32 (the direct final block: stride 1).
+    Returns the one-element fp32 device tensor mean((LeakyReLU_slope(l) - target)^2); ``d_logits`` (same shape; bf16
+    for 16-bit logits, fp32 for fp32 logits) gets grad_scale * (a - target) * LeakyReLU'(l) in column 0 (16-bit rows:
+    zeros elsewhere)."""
+    _chk(logits_rows, (BF16, F16, F32), "logits", 2)
     m, stride = logits_rows.shape
+    fmt = 2 if logits_rows.dtype == F32 else int(logits_rows.dtype == F16)
     if d_logits is not None:
-        _chk(d_logits, BF16, "d_logits", 2)
+        _chk(d_logits, F32 if fmt == 2 else BF16, "d_logits", 2)
         if d_logits.shape != logits_rows.shape:
             raise ValueError("pd_lsgan: d_logits shape")
     buf = torch.empty(1 + L.lib().pti_pd_lsgan_blocks(m), dtype=F32, device=logits_rows.device)
-    L.check(L.lib().pti_pd_lsgan(_ptr(logits_rows), int(logits_rows.dtype == F16), stride, m, float(target), float(slope),
-                                 float(grad_scale), _ptr(buf), _ptr(d_logits), _stream()), "pti_pd_lsgan")
+    L.check(L.lib().pti_pd_lsgan(_ptr(logits_rows), fmt, stride, m, float(target), float(slope), float(grad_scale), _ptr(buf),
+                                 _ptr(d_logits), _stream()), "pti_pd_lsgan")
     return buf[:1]
+
+
+def pd_final_fwd(y_prev, norm, w16c, bias, logits, *, slope=0.2):
+    """Final discriminator block without a patch matrix: logits fp32 [n, h-1, w-1] = conv4x4(LeakyReLU(norm(y_prev)), w) + b;
+    w16c fp32 [16*c] (tap-major), bias fp32 [>=1]."""
+    _chk(y_prev, BF16, "y_prev", 4)
+    _chk(logits, F32, "logits", 3)
+    n, h, w, c = y_prev.shape
+    if tuple(logits.shape) != (n, h - 1, w - 1) or w16c.numel() != 16 * c:
+        raise ValueError("pd_final_fwd: shapes")
+    L.check(L.lib().pti_pd_final_fwd(_ptr(y_prev), _ptr(norm), _ptr(w16c), _ptr(bias), _ptr(logits), n, h, w, c, float(slope),
+                                     _stream()), "pti_pd_final_fwd")
+    return logits
+
+
+def pd_final_dgrad(d_logits, y_prev, norm, w16c, g, *, slope=0.2):
+    """-> (g, sums | None) like pd_col2im, for the direct final block (d_logits fp32 [n, h-1, w-1])."""
+    _chk(d_logits, F32, "d_logits")
+    _chk(y_prev, BF16, "y_prev", 4)
+    _chk(g, BF16, "g", 4)
+    n, h, w, c = y_prev.shape
+    if d_logits.numel() != n * (h - 1) * (w - 1) or g.shape != y_prev.shape or w16c.numel() != 16 * c:
+        raise ValueError("pd_final_dgrad: shapes")
+    part = sums = None
+    if norm is not None:
+        part = torch.empty(n, L.lib().pti_pd_col2im_blocks(n, h * w, c), c, 2, dtype=F32, device=g.device)
+    L.check(L.lib().pti_pd_final_dgrad(_ptr(d_logits), _ptr(y_prev), _ptr(norm), _ptr(w16c), _ptr(g), _ptr(part), n, h, w, c,
+                                       float(slope), _stream()), "pti_pd_final_dgrad")
+    if part is not None:
+        sums = torch.empty(n, c, 2, dtype=F32, device=g.device)
+        L.check(L.lib().pti_gn_sums_finalize(_ptr(part), _ptr(sums), n, part.shape[1], 2 * c, _stream()), "pti_gn_sums_finalize")
+    return g, sums
+
+
+def pd_final_wgrad(d_logits, y_prev, norm, *, slope=0.2):
+    """-> fp32 [16*c + 8]: {dw[16][c], dbias, 0...} of the direct final block (block partials summed in block order)."""
+    _chk(d_logits, F32, "d_logits")
+    _chk(y_prev, BF16, "y_prev", 4)
+    n, h, w, c = y_prev.shape
+    if d_logits.numel() != n * (h - 1) * (w - 1):
+        raise ValueError("pd_final_wgrad: shapes")
+    blocks = L.lib().pti_pd_final_wgrad_blocks(n, h, w)
+    row = 16 * c + 8
+    part = torch.empty(blocks, row, dtype=F32, device=y_prev.device)
+    L.check(L.lib().pti_pd_final_wgrad(_ptr(d_logits), _ptr(y_prev), _ptr(norm), _ptr(part), n, h, w, c, float(slope), _stream()),
+            "pti_pd_final_wgrad")
+    out = torch.empty(row, dtype=F32, device=y_prev.device)
+    L.check(L.lib().pti_gn_sums_finalize(_ptr(part), _ptr(out), 1, blocks, row, _stream()), "pti_gn_sums_finalize")
+    return out

@@ -116,24 +116,63 @@ def test_instance_norm_stats_and_backward(dev, c, h, w):
     assert _rel(dy.cpu().float(), yf.grad) < 5e-3
 
 
-@pytest.mark.parametrize("real,f16", [(True, False), (False, False), (True, True)])
-def test_lsgan_vs_oracle(dev, real, f16):
+@pytest.mark.parametrize("real,fmt", [(True, "bf16"), (False, "bf16"), (True, "f16"), (True, "f32"), (False, "f32")])
+def test_lsgan_vs_oracle(dev, real, fmt):
+    """16-bit padded rows (logit in column 0 of 32) and the fp32 [M,1] form the direct final block produces."""
     from oracle.patch_discriminator import patch_adversarial_loss
     from pti_ldm_vae_amd import ops
     torch.manual_seed(5)
     m = 2 * 30 * 30
-    rows = torch.zeros(m, 32)
-    rows[:, 0] = torch.randn(m) * 1.5 + 0.3
-    rows[:, 1:] = 7.0                                    # the padding columns must not matter
-    rows = rows.to(torch.float16 if f16 else BF16)
-    d = torch.full((m, 32), 9.0, dtype=BF16, device=dev)
+    lg = torch.randn(m) * 1.5 + 0.3
+    if fmt == "f32":
+        rows = lg.view(m, 1).clone()
+        d = torch.full((m, 1), 9.0, device=dev)
+    else:
+        rows = torch.full((m, 32), 7.0)                  # the padding columns must not matter
+        rows[:, 0] = lg
+        rows = rows.to(torch.float16 if fmt == "f16" else BF16)
+        d = torch.full((m, 32), 9.0, dtype=BF16, device=dev)
     loss = ops.pd_lsgan(rows.to(dev), target=1.0 if real else 0.0, slope=0.05, grad_scale=0.3 * 2.0 / m, d_logits=d)
     lf = rows[:, 0].float().requires_grad_(True)
     want = patch_adversarial_loss(lf.view(2, 1, 30, 30), target_is_real=real, for_discriminator=True)
     (0.3 * want).backward()
     assert abs(float(loss) - float(want.detach())) < 1e-5 * max(1.0, float(want.detach()))
-    assert float(d[:, 1:].abs().max()) == 0.0
-    assert _rel(d[:, 0].cpu().float(), lf.grad) < 4e-3   # bf16 rounding of the stored gradient
+    if fmt != "f32":
+        assert float(d[:, 1:].abs().max()) == 0.0
+    assert _rel(d[:, 0].cpu().float(), lf.grad) < (1e-6 if fmt == "f32" else 4e-3)   # bf16 rounding of the stored gradient
+
+
+@pytest.mark.parametrize("c,h,w", [(256, 31, 31), (64, 7, 5), (32, 9, 12)])
+def test_final_block_direct_kernels(dev, c, h, w):
+    """The one-output-channel final block without a patch matrix: forward, data gradient (+ LeakyReLU' + InstanceNorm
+    partial sums) and weight / bias gradient against torch autograd of conv2d(leaky_relu(instance_norm(y)))."""
+    from pti_ldm_vae_amd import ops
+    torch.manual_seed(c + h)
+    n = 3
+    y = (torch.randn(n, h, w, c) * 1.5 + 0.2).to(BF16)
+    t = ops.pd_in_stats(y.to(dev), 1e-5)
+    tc = t.cpu()
+    wt = (torch.randn(1, c, 4, 4) * 0.05).requires_grad_(True)
+    bias = torch.tensor([0.3], requires_grad=True)
+    xh = ((y.float() - tc[:, None, None, :, 0]) * tc[:, None, None, :, 1]).requires_grad_(True)    # same table on both sides
+    out = F.conv2d(F.leaky_relu(xh, 0.2).permute(0, 3, 1, 2), wt, bias, padding=1)
+    dl = torch.randn_like(out)
+    out.backward(dl)
+    w16c = wt.detach().permute(0, 2, 3, 1).reshape(-1).contiguous().to(dev)        # [ky][kx][c]
+    bd = torch.zeros(32, device=dev)
+    bd[0] = 0.3
+    logits = torch.empty(n, h - 1, w - 1, device=dev)
+    ops.pd_final_fwd(y.to(dev), t, w16c, bd, logits, slope=0.2)
+    assert _rel(logits.cpu(), out.detach()[:, 0]) < 1e-5
+    g = torch.empty(n, h, w, c, dtype=BF16, device=dev)
+    g, sums = ops.pd_final_dgrad(dl[:, 0].contiguous().to(dev), y.to(dev), t, w16c, g, slope=0.2)
+    assert _rel(g.float().cpu(), xh.grad) < 4e-3
+    s_want = torch.stack([xh.grad.sum((1, 2)), (xh.grad * xh.detach()).sum((1, 2))], -1)
+    assert _rel(sums.cpu(), s_want) < 1e-4
+    gw = ops.pd_final_wgrad(dl[:, 0].contiguous().to(dev), y.to(dev), t, slope=0.2).cpu()
+    assert _rel(gw[:16 * c], wt.grad.permute(0, 2, 3, 1).reshape(-1)) < 1e-4
+    assert abs(float(gw[16 * c]) - float(bias.grad)) < 1e-4 * max(1.0, abs(float(bias.grad)))
+    assert float(gw[16 * c + 1:].abs().max()) == 0.0
 
 
 # ---- engine ------------------------------------------------------------------------------------------------------------
@@ -152,7 +191,8 @@ def _pin_forward_state(ref, ctxs):
         def hook(m, inp, out):
             ctx = ctxs[state["call"] // len(blocks)]
             state["call"] += 1
-            y = ctx.y[i][..., :out.shape[1]].float().permute(0, 3, 1, 2).cpu()
+            yv = ctx.y[i]      # last block: fp32 logits [B,Ho,Wo]; the others: bf16 NHWC conv outputs
+            y = yv.unsqueeze(1).cpu() if yv.dim() == 3 else yv[..., :out.shape[1]].float().permute(0, 3, 1, 2).cpu()
             return out + (y - out).detach()
         return hook
     for i, blk in enumerate(blocks):
