@@ -253,6 +253,9 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--config", default=os.path.join(ROOT, "config", "vae_dente_no_adv.json"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--perceptual", action="store_true",
+                    help="add the config's perceptual_weight * LPIPS(SqueezeNet-1.1) term (models/perceptual.py, torch ops on "
+                         "the device; RANDOM-INIT weights: the pretrained files cannot be fetched -- same arithmetic and cost)")
     ap.add_argument("--adv", action="store_true",
                     help="time the step of epochs > 5 of an adv_enabled config: + PatchDiscriminator generator term and "
                          "discriminator step (train_vae.py:399-401,447-458); needs a 1-channel model")
@@ -281,7 +284,7 @@ def main():
     torch.cuda.set_device(dev)
 
     global PMC_WORKLOAD
-    PMC_WORKLOAD = f"{os.path.basename(args.config)}:b{args.batch}:{args.size}" + (":adv" if args.adv else "")
+    PMC_WORKLOAD = f"{os.path.basename(args.config)}:b{args.batch}:{args.size}" + (":adv" if args.adv else "") + (":perceptual" if args.perceptual else "")
     cfg = read_config(args.config)
     if "regressor_def" in cfg or "regression_train" in cfg:      # BASELINE config 5: regression on frozen latents
         return bench_regression(args, cfg, dev, world, rank, dist)
@@ -300,8 +303,13 @@ def main():
         from pti_ldm_vae_amd.models import PatchDiscriminator
         disc = PatchDiscriminator(spatial_dims=2, num_layers_d=3, channels=32, in_channels=1, out_channels=1,
                                   norm="INSTANCE").to(dev)
+    perc = None
+    if args.perceptual:
+        from pti_ldm_vae_amd.models import PerceptualLoss
+        perc = PerceptualLoss(spatial_dims=2, network_type="squeeze", allow_random_init=True).to(dev)
     trainer = VAETrainer(model, lr=tr["lr"], world_size=world, recon_loss=tr["recon_loss"], kl_weight=tr["kl_weight"],
-                         rank_eps_offset=rank, ar=ar, discriminator=disc, adv_weight=float(tr.get("adv_weight", 0.0)))
+                         rank_eps_offset=rank, ar=ar, discriminator=disc, adv_weight=float(tr.get("adv_weight", 0.0)),
+                         perceptual=perc, perceptual_weight=float(tr.get("perceptual_weight", 1.0)) if perc is not None else 0.0)
     step_kw = {"adversarial": True} if args.adv else {}
     images = synthetic_batch(args.batch, cfg_def["in_channels"], args.size, dev, seed=42 + rank)
     attrs = None
@@ -388,11 +396,12 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"config/{os.path.basename(args.config)} {args.size}x{args.size}x{cfg_def['in_channels']} "
                                    f"batch {args.batch}/GPU: fwd + L1 + 1e-3*KL{' + 0.5*AR-VAE(6 attributes)' if ar else ''}"
+                                   + (f" + {trainer.perceptual_weight}*LPIPS(SqueezeNet-1.1, random-init weights, torch ops)" if args.perceptual else "")
                                    + (f" + {trainer.adv_weight}*LSGAN(PatchDiscriminator) + bwd + all-reduce + Adam, then the "
                                       "discriminator step (fake + real pass, bwd, all-reduce, Adam) "
-                                      "(perceptual term omitted: unavailable offline)" if args.adv else
-                                      " + bwd + all-reduce + Adam (perceptual term omitted: unavailable offline; adversarial "
-                                      "branch inactive before epoch 6, --adv times it)"),
+                                      + ("" if args.perceptual else "(perceptual term omitted: --perceptual times it)") if args.adv else
+                                      " + bwd + all-reduce + Adam (" + ("" if args.perceptual else "perceptual term omitted: "
+                                      "--perceptual times it; ") + "adversarial branch inactive before epoch 6, --adv times it)"),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss, 5)},
             "model_tflops_per_gpu": round(per_gpu * gflop_img / 1e3, 1) if gflop_img else None,
             "frac_of_mfma_peak_end_to_end": round(per_gpu * gflop_img / 1e3 / PEAK_BF16_TFLOPS, 4) if gflop_img else None,

@@ -1,0 +1,148 @@
+"""Perceptual (LPIPS) term of the training loss — SURVEY 8f N3.
+
+Reference: ``vae_scripts/train_vae.py:299`` builds ``monai.losses.PerceptualLoss(spatial_dims=2, network_type="squeeze")``
+(= the ``lpips`` package's ``LPIPS(net="squeeze")`` on torchvision's SqueezeNet-1.1 features, result averaged over the
+batch) and ``:395-397`` applies it to ``ensure_three_channels(reconstruction)`` vs ``ensure_three_channels(images)`` with
+weight 1.0 in every shipped config.
+
+Status here: the pretrained weights (torchvision ``squeezenet1_1`` + lpips ``squeeze.pth``) cannot be fetched — there is
+no network — and neither ``lpips`` nor ``torchvision`` is installed, so the network is RESTATED below in plain torch with
+the two packages' ``state_dict`` key names, and ``PerceptualLoss(weights=(backbone_file, lin_file))`` loads files the
+user supplies locally (``torch.load(..., weights_only=True)``).  The network runs as ordinary torch ops on the HIP device
+(it is a fixed feature extractor next to the hot path, 2 % of the parameters; hand-written kernels would buy little and
+could not be checked against real weights here); its gradient w.r.t. the reconstruction is taken by autograd and ADDED to
+the native step's ``d_recon`` (``VAETrainer(perceptual=...)``), so the VAE itself still runs on the HIP engine.
+Parity: UNPINNED (restated from the published structure of both packages; no weights, no reference output available).
+Without supplied weights the class refuses to build unless ``allow_random_init=True`` (tests, throughput runs).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..utils.losses import ensure_three_channels
+
+LPIPS_CHANNELS = (64, 128, 256, 384, 384, 512, 512)
+
+
+class Fire(nn.Module):
+    """torchvision ``squeezenet.Fire`` (key names ``squeeze``, ``expand1x1``, ``expand3x3``)."""
+
+    def __init__(self, cin: int, squeeze: int, e1: int, e3: int):
+        super().__init__()
+        self.squeeze = nn.Conv2d(cin, squeeze, 1)
+        self.expand1x1 = nn.Conv2d(squeeze, e1, 1)
+        self.expand3x3 = nn.Conv2d(squeeze, e3, 3, padding=1)
+
+    def forward(self, x):
+        x = F.relu(self.squeeze(x))
+        return torch.cat([F.relu(self.expand1x1(x)), F.relu(self.expand3x3(x))], 1)
+
+
+class _Pool(nn.Module):
+    def forward(self, x):
+        return F.max_pool2d(x, 3, 2, ceil_mode=True)
+
+
+class _Relu(nn.Module):
+    def forward(self, x):
+        return F.relu(x)
+
+
+def squeezenet1_1_features() -> nn.Sequential:
+    """``torchvision.models.squeezenet1_1().features`` (indices 0..12 => keys ``features.N...`` of its state_dict)."""
+    return nn.Sequential(
+        nn.Conv2d(3, 64, 3, stride=2), _Relu(), _Pool(),
+        Fire(64, 16, 64, 64), Fire(128, 16, 64, 64), _Pool(),
+        Fire(128, 32, 128, 128), Fire(256, 32, 128, 128), _Pool(),
+        Fire(256, 48, 192, 192), Fire(384, 48, 192, 192), Fire(384, 64, 256, 256), Fire(512, 64, 256, 256))
+
+
+class _Lin(nn.Module):
+    """lpips ``NetLinLayer``: Dropout (index 0, inactive in eval) + 1x1 conv without bias (index 1) => ``linK.model.1.weight``."""
+
+    def __init__(self, cin: int):
+        super().__init__()
+        self.model = nn.Sequential(nn.Identity(), nn.Conv2d(cin, 1, 1, bias=False))
+
+    def forward(self, x):
+        return self.model(x)
+
+
+class SqueezeLPIPS(nn.Module):
+    """``lpips.LPIPS(net="squeeze", lpips=True, spatial=False)`` in eval mode: input scaling, seven SqueezeNet-1.1
+    feature taps (``features[0:2], [2:5], [5:8], [8:10], [10:11], [11:12], [12:13]``), channel-unit-normalised squared
+    differences weighted by the ``lin`` layers, spatially averaged and summed.  Returns [N,1,1,1]."""
+
+    SLICES = ((0, 2), (2, 5), (5, 8), (8, 10), (10, 11), (11, 12), (12, 13))
+
+    def __init__(self):
+        super().__init__()
+        self.features = squeezenet1_1_features()
+        for k, c in enumerate(LPIPS_CHANNELS):
+            setattr(self, f"lin{k}", _Lin(c))
+        self.register_buffer("shift", torch.tensor([-0.030, -0.088, -0.188]).view(1, 3, 1, 1), persistent=False)
+        self.register_buffer("scale", torch.tensor([0.458, 0.448, 0.450]).view(1, 3, 1, 1), persistent=False)
+        for p in self.parameters():
+            p.requires_grad_(False)
+        self.eval()
+
+    def _taps(self, x):
+        out = []
+        for a, b in self.SLICES:
+            for i in range(a, b):
+                x = self.features[i](x)
+            out.append(x)
+        return out
+
+    def forward(self, in0, in1):
+        f0 = self._taps((in0 - self.shift) / self.scale)
+        f1 = self._taps((in1 - self.shift) / self.scale)
+        total = 0.0
+        for k, (a, b) in enumerate(zip(f0, f1)):
+            a = a / (a.pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
+            b = b / (b.pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
+            total = total + getattr(self, f"lin{k}")((a - b) ** 2).mean((2, 3), keepdim=True)
+        return total
+
+    # ---- local weight files ------------------------------------------------------------------------------------------
+    def load_local_weights(self, backbone_file: str, lin_file: str) -> None:
+        """``backbone_file``: torchvision's ``squeezenet1_1-*.pth`` state_dict (keys ``features.N.*``; the classifier's
+        keys are ignored); ``lin_file``: lpips' ``weights/v0.1/squeeze.pth`` (keys ``linK.model.1.weight``).  Both are
+        read with ``weights_only=True``.  Raises if a key the network needs is missing or has the wrong shape."""
+        bb = torch.load(backbone_file, map_location="cpu", weights_only=True)
+        lin = torch.load(lin_file, map_location="cpu", weights_only=True)
+        own = self.state_dict()
+        picked = {}
+        for k in own:
+            src = bb if k.startswith("features.") else lin
+            if k not in src:
+                raise KeyError(f"perceptual weights: '{k}' not found in {'backbone' if src is bb else 'lin'} file")
+            if tuple(src[k].shape) != tuple(own[k].shape):
+                raise ValueError(f"perceptual weights: shape of '{k}' is {tuple(src[k].shape)}, expected {tuple(own[k].shape)}")
+            picked[k] = src[k]
+        self.load_state_dict(picked, strict=True)
+
+
+class PerceptualLoss(nn.Module):
+    """Counterpart of ``monai.losses.PerceptualLoss(spatial_dims=2, network_type="squeeze")`` as the reference uses it:
+    ``forward(input, target) -> scalar`` = batch mean of LPIPS(input, target); 1-channel inputs are repeated to three
+    (``ensure_three_channels``, which the reference applies itself before the call — doing it again is a no-op)."""
+
+    def __init__(self, spatial_dims: int = 2, network_type: str = "squeeze", weights: tuple[str, str] | None = None,
+                 allow_random_init: bool = False):
+        super().__init__()
+        if spatial_dims != 2 or network_type != "squeeze":
+            raise ValueError("pti_ldm_vae_amd PerceptualLoss: spatial_dims=2, network_type='squeeze' (the reference's call)")
+        self.net = SqueezeLPIPS()
+        if weights is not None:
+            self.net.load_local_weights(*weights)
+        elif not allow_random_init:
+            raise RuntimeError("PerceptualLoss: the pretrained SqueezeNet-1.1 / LPIPS weights are not available offline. "
+                               "Pass weights=(squeezenet1_1_state_dict.pth, lpips_squeeze.pth) from local files "
+                               "(or allow_random_init=True for tests / throughput runs).")
+        self.pretrained = weights is not None
+
+    def forward(self, input: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        return self.net(ensure_three_channels(input.float()), ensure_three_channels(target.float())).mean()

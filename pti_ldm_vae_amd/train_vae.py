@@ -16,9 +16,10 @@ What is different, on purpose:
     6 on, train_vae.py:266-279,399-401,447-458) runs natively (``models/patch_discriminator.py``, ``disc_engine.py``);
     ``discriminator_last.pt`` / ``discriminator_epoch{E}.pth`` and the ``discriminator_state_dict`` /
     ``optimizer_d_state_dict`` checkpoint entries are written and read like the reference's;
-  * the perceptual (LPIPS) term is NOT available here (it needs packages/weights that are not installable offline):
-    ``perceptual_weight`` is read and reported, and must be 0 — or pass ``--ignore-unavailable-terms`` to train
-    without it and a warning;
+  * the perceptual (LPIPS) term needs pretrained weights that cannot be fetched here: pass
+    ``--perceptual-weights squeezenet1_1.pth lpips_squeeze.pth`` (local files) and it is part of the step
+    (``models/perceptual.py``: torch ops on the device, gradient added to the native backward); without them a
+    non-zero ``perceptual_weight`` is refused — or pass ``--ignore-unavailable-terms`` to train without it and a warning;
   * the AR-VAE term (``regularized_attributes``) IS part of the native step (``pti_ar_vae_loss``);
   * data: without ``--synthetic`` the TIFF directory of the config is read through the device input pipeline
     (``pti_ldm_vae_amd.data``: host decode -> one H2D copy -> GPU resize + masked z-score; attribute JSONs joined
@@ -38,7 +39,7 @@ from pathlib import Path
 
 import torch
 
-from .models import PatchDiscriminator, VAEModel, compute_total_loss
+from .models import PatchDiscriminator, PerceptualLoss, VAEModel, compute_total_loss
 from .trainer import ARSettings, VAETrainer, prepare_batch
 from .utils import read_config, resolve_ar_settings
 from .utils.distributed import setup_ddp
@@ -60,6 +61,8 @@ def parse_args(argv=None):
     p.add_argument("--synthetic", type=int, default=0, help="train on N synthetic images (no file I/O)")
     p.add_argument("--log-every", type=int, default=20)
     p.add_argument("--ignore-unavailable-terms", action="store_true")
+    p.add_argument("--perceptual-weights", nargs=2, metavar=("SQUEEZENET_PTH", "LPIPS_SQUEEZE_PTH"), default=None,
+                   help="local weight files of the perceptual loss: torchvision squeezenet1_1 state_dict and lpips v0.1 squeeze.pth")
     p.add_argument("--adv-start-epoch", type=int, default=6,
                    help="first epoch with the adversarial branch on (the reference hard-codes `epoch > 5`)")
     p.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
@@ -215,8 +218,14 @@ def main(argv=None):
     ar_enabled, ar_gamma, _, _ = resolve_ar_settings(tr, getattr(args, "regularized_attributes", {}))
     adv_enabled = bool(tr.get("adv_enabled", True))
     unavailable = []
-    if float(tr.get("perceptual_weight", 0.0)) != 0.0:
-        unavailable.append(f"perceptual_weight={tr['perceptual_weight']} (LPIPS needs lpips+torchvision+weights)")
+    perceptual_weight = float(tr.get("perceptual_weight", 0.0))
+    perceptual = None
+    if perceptual_weight != 0.0 and args.perceptual_weights:
+        perceptual = PerceptualLoss(spatial_dims=2, network_type="squeeze", weights=tuple(args.perceptual_weights)).to(device)
+    elif perceptual_weight != 0.0:
+        unavailable.append(f"perceptual_weight={tr['perceptual_weight']} (the pretrained SqueezeNet/LPIPS weights are not "
+                           "available offline: supply them with --perceptual-weights)")
+        perceptual_weight = 0.0
     if unavailable:
         msg = "terms not available in the native trainer: " + "; ".join(unavailable)
         if not args.ignore_unavailable_terms:
@@ -242,7 +251,8 @@ def main(argv=None):
                               norm="INSTANCE").to(device) if adv_enabled else None
     adv_weight = float(tr.get("adv_weight", 0.0))
     trainer = VAETrainer(model, lr=tr["lr"], world_size=world, process_group=pg, recon_loss=tr.get("recon_loss", "l1"),
-                         kl_weight=tr["kl_weight"], rank_eps_offset=rank, ar=ar, discriminator=disc, adv_weight=adv_weight)
+                         kl_weight=tr["kl_weight"], rank_eps_offset=rank, ar=ar, discriminator=disc, adv_weight=adv_weight,
+                         perceptual=perceptual, perceptual_weight=perceptual_weight)
     opt_d = trainer.opt_d if disc is not None else None
     start_epoch, best_val, total_step, best_epoch_saved = load_checkpoint(args, model, trainer.opt, device, disc, opt_d)
     model.autoencoder.mark_weights_dirty()
@@ -279,7 +289,8 @@ def main(argv=None):
             if log is not None and step % args.log_every == 0:
                 rec = {"train/step": total_step, "train/recon_loss": out["recon"].item(),
                        "train/kl_loss": out["kl"].item(), "train/loss_total": out["loss"].item(),
-                       "train/perceptual_loss": 0.0,      # W&B names and weighting of train_vae.py:467-468
+                       "train/perceptual_loss": out["perceptual"].item() if perceptual is not None else 0.0,
+                       # W&B names and weighting of train_vae.py:467-468
                        "train/adv_gen_loss": adv_weight * out["adv_gen"].item() if adv_on else 0.0,
                        "train/adv_disc_loss": adv_weight * out["adv_disc"].item() if adv_on else 0.0}
                 if ar is not None:   # W&B names of train_vae.py:471-478
@@ -289,7 +300,7 @@ def main(argv=None):
                 log.write(json.dumps(rec) + "\n")
                 log.flush()
         if epoch % val_interval == 0:
-            rsum = ksum = asum = gsum = torch.zeros((), device=device)
+            rsum = ksum = asum = gsum = psum = torch.zeros((), device=device)
             nb = 0
             for batch in data.batches(epoch, train=False):
                 images, attrs = prepare_batch(batch, device, ar_enabled)
@@ -297,10 +308,13 @@ def main(argv=None):
                 rsum, ksum, nb = rsum + v["recon"], ksum + v["kl"], nb + 1
                 if adv_on:
                     gsum = gsum + v["adv_gen"]
+                if perceptual is not None:
+                    psum = psum + v["perceptual"]
                 if ar is not None:
                     asum = asum + v["ar"]
-            val_recon, val_kl, val_ar, val_gen = ((t / max(nb, 1)).item() for t in (rsum, ksum, asum, gsum))
-            val_total = compute_total_loss(val_recon, val_kl, 0.0, val_gen, val_ar, kl_weight=kl_w, perceptual_weight=0.0,
+            val_recon, val_kl, val_ar, val_gen, val_p = ((t / max(nb, 1)).item() for t in (rsum, ksum, asum, gsum, psum))
+            val_total = compute_total_loss(val_recon, val_kl, val_p, val_gen, val_ar, kl_weight=kl_w,
+                                           perceptual_weight=perceptual_weight,
                                            adv_weight=adv_weight if adv_on else 0.0, ar_gamma=ar_gamma,
                                            ar_vae_enabled=ar_enabled)
             torch.cuda.synchronize()
@@ -308,7 +322,7 @@ def main(argv=None):
             if rank == 0:
                 print(f"Epoch {epoch} val_loss: {val_recon:.4f} | Time: {dt:.1f}s | {seen * world / dt:.1f} img/s")
                 rec = {"epoch": epoch, "val/recon_loss": val_recon, "val/kl_loss": val_kl, "val/loss_total": val_total,
-                       "val/perceptual_loss": 0.0, "time_per_epoch": dt}
+                       "val/perceptual_loss": val_p, "time_per_epoch": dt}
                 if ar is not None:
                     rec["val/ar_loss_total"] = val_ar
                 log.write(json.dumps(rec) + "\n")

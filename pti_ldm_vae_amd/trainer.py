@@ -11,10 +11,11 @@ device tensors.  The AR-VAE term (``compute_ar_vae_loss``, losses.py:69-166, cal
 
 The adversarial branch (train_vae.py:399-401 generator term, :447-458 discriminator step; active when ``adv_enabled``
 and ``epoch > 5``) runs on the PatchDiscriminator engine (``disc_engine.py``): pass ``discriminator=`` /
-``adv_weight=`` and call ``step(..., adversarial=True)``.  The perceptual (LPIPS) term is NOT part of this path
-(weights unavailable offline -- DESIGN.md 6); ``perceptual_weight`` must be 0 here and the drop-in autograd path
-(``VAEModel.forward`` + any torch loss) remains available for everything else.  No ``.item()`` on the step path: loss
-scalars come back as device tensors.
+``adv_weight=`` and call ``step(..., adversarial=True)``.  The perceptual (LPIPS) term (train_vae.py:395-397) is a
+torch module the caller supplies (``perceptual=``, e.g. ``models.perceptual.PerceptualLoss`` with locally provided
+weights -- they cannot be fetched here): it is evaluated on the reconstruction under autograd and its
+gradient joins ``d_recon`` before the HIP backward.  No ``.item()`` on the step path: loss scalars come back as device
+tensors.
 """
 from __future__ import annotations
 
@@ -108,7 +109,8 @@ class VAETrainer:
     def __init__(self, model, *, lr: float, world_size: int = 1, process_group=None, recon_loss: str = "l1",
                  kl_weight: float = 1e-3, kl_input_is_logvar: bool = True, bucket_bytes: int = 4 << 20,
                  rank_eps_offset: int = 0, ar: ARSettings | None = None, discriminator=None, adv_weight: float = 0.0,
-                 lr_d: float | None = None, adv_no_activation_leastsq: bool = False):
+                 lr_d: float | None = None, adv_no_activation_leastsq: bool = False, perceptual=None,
+                 perceptual_weight: float = 0.0):
         self.model = model
         self.net = net = model.autoencoder
         self.eng = net.engine()
@@ -145,6 +147,10 @@ class VAETrainer:
             self.reducer_d = FlatGradAllReducer(discriminator.grad_arena, process_group, bucket_bytes)
             broadcast_parameters(discriminator.param_arena, process_group)
             discriminator.mark_weights_dirty()
+        # perceptual term: any torch module  f(reconstruction, images) -> scalar  on the device (frozen weights)
+        self.perceptual, self.perceptual_weight = perceptual, float(perceptual_weight)
+        if perceptual is None and self.perceptual_weight != 0.0:
+            raise ValueError("perceptual_weight != 0 needs a perceptual loss module (VAETrainer(perceptual=...))")
         self.ar = ar
         if ar is not None:
             if max(ar.channels) >= net.latent_channels:
@@ -224,6 +230,20 @@ class VAETrainer:
             self.opt_d.step(grad_scale=1.0 / self.world)
         return 0.5 * (l_fake + l_real)
 
+    def _perceptual_term(self, recon, images, d_recon):
+        """train_vae.py:395-397: p_loss = loss_perceptual(ensure_three_channels(recon), ensure_three_channels(images));
+        adds perceptual_weight * d p_loss / d recon into ``d_recon`` (when given)."""
+        from .utils.losses import ensure_three_channels
+        if d_recon is None:
+            with torch.no_grad():
+                return self.perceptual(ensure_three_channels(recon.float()), ensure_three_channels(images.float()))
+        r = recon.detach().requires_grad_(True)
+        with torch.enable_grad():
+            p = self.perceptual(ensure_three_channels(r.float()), ensure_three_channels(images.float()))
+            (g,) = torch.autograd.grad(p, r)
+        d_recon.add_(g, alpha=self.perceptual_weight)
+        return p.detach()
+
     def step(self, images: torch.Tensor, eps: torch.Tensor | None = None, attributes: dict | None = None,
              adversarial: bool = False):
         """One optimiser step on ``images`` [B,C,H,W] fp32 (already on the device).  Returns a dict of
@@ -231,7 +251,8 @@ class VAETrainer:
         the AR-VAE term is on, which needs ``attributes`` = {name: [B] tensor} -- with no host sync with THIS step
         (see ``max_steps_in_flight``).  ``adversarial`` (the reference's ``adv_enabled and epoch > 5``): the generator
         loss gains adv_weight * the least-squares term through the discriminator, then the discriminator takes its
-        own optimiser step; adds {"adv_gen", "adv_disc"} (unweighted, as the reference logs them before weighting)."""
+        own optimiser step; adds {"adv_gen", "adv_disc"} (unweighted, as the reference logs them before weighting).
+        With a perceptual module and a non-zero ``perceptual_weight`` the result also holds {"perceptual"}."""
         if adversarial and self.disc is None:
             raise ValueError("step(adversarial=True) needs VAETrainer(discriminator=...)")
         net, eng, red = self.net, self.eng, self.reducer
@@ -254,6 +275,9 @@ class VAETrainer:
             ar_out = None
             if self.ar is not None:   # + gamma * AR-VAE(z_mu.mean(h, w)): its gradient goes straight into d_mu
                 ar_out = self._ar_term(mu, attributes, d_mu)
+            p_loss = None
+            if self.perceptual is not None and self.perceptual_weight != 0.0:
+                p_loss = self._perceptual_term(recon, images, d_recon)
             adv_ctx = None
             if adversarial:           # + adv_weight * generator term: its gradient w.r.t. the reconstruction joins d_recon
                 adv_gen, adv_ctx = self._adv_generator_term(recon, d_recon)
@@ -275,6 +299,9 @@ class VAETrainer:
         if ar_out is not None:
             res["ar"], res["ar_per_attr"], res["ar_pairs"] = ar_out
             res["loss"] = res["loss"] + self.ar.gamma * ar_out[0]
+        if p_loss is not None:
+            res["perceptual"] = p_loss
+            res["loss"] = res["loss"] + self.perceptual_weight * p_loss
         if adversarial:
             res["adv_gen"], res["adv_disc"] = adv_gen[0], adv_disc[0]
             res["loss"] = res["loss"] + self.adv_weight * adv_gen[0]
@@ -295,6 +322,8 @@ class VAETrainer:
         res = {"recon": out2[0], "kl": out2[1]}
         if self.ar is not None:
             res["ar"], res["ar_per_attr"], res["ar_pairs"] = self._ar_term(mu, attributes, None)
+        if self.perceptual is not None and self.perceptual_weight != 0.0:
+            res["perceptual"] = self._perceptual_term(recon, images, None)
         if adversarial:
             if self.disc is None:
                 raise ValueError("eval_losses(adversarial=True) needs VAETrainer(discriminator=...)")

@@ -1,0 +1,83 @@
+"""CPU tests of the perceptual-loss module (``models/perceptual.py``): torchvision / lpips state_dict key
+names and shapes, the local-file weight loader (with files written here -- the real pretrained files cannot be fetched),
+refusal without weights, LPIPS's defining properties (zero for identical inputs, symmetric, batch mean)."""
+import pytest
+import torch
+
+# torchvision.models.squeezenet1_1().features: conv at index 0, Fire modules at 3,4,6,7,9,10,11,12 (published layout)
+FIRES = {3: (64, 16, 64), 4: (128, 16, 64), 6: (128, 32, 128), 7: (256, 32, 128), 9: (256, 48, 192), 10: (384, 48, 192),
+         11: (384, 64, 256), 12: (512, 64, 256)}
+
+
+def _expected_keys():
+    keys = {"features.0.weight": (64, 3, 3, 3), "features.0.bias": (64,)}
+    for i, (cin, sq, ex) in FIRES.items():
+        keys[f"features.{i}.squeeze.weight"], keys[f"features.{i}.squeeze.bias"] = (sq, cin, 1, 1), (sq,)
+        keys[f"features.{i}.expand1x1.weight"], keys[f"features.{i}.expand1x1.bias"] = (ex, sq, 1, 1), (ex,)
+        keys[f"features.{i}.expand3x3.weight"], keys[f"features.{i}.expand3x3.bias"] = (ex, sq, 3, 3), (ex,)
+    for k, c in enumerate((64, 128, 256, 384, 384, 512, 512)):
+        keys[f"lin{k}.model.1.weight"] = (1, c, 1, 1)
+    return keys
+
+
+def test_state_dict_matches_the_two_packages_layouts():
+    from pti_ldm_vae_amd.models import SqueezeLPIPS
+    net = SqueezeLPIPS()
+    got = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert got == _expected_keys()
+    assert sum(p.numel() for p in net.features.parameters()) == 722_496      # squeezenet1_1 without its classifier
+    assert not any(p.requires_grad for p in net.parameters()) and not net.training
+    taps = net._taps(torch.randn(1, 3, 256, 256))
+    assert [tuple(t.shape[1:]) for t in taps] == [(64, 127, 127), (128, 63, 63), (256, 31, 31), (384, 15, 15), (384, 15, 15),
+                                                   (512, 15, 15), (512, 15, 15)]
+
+
+def test_local_weight_files_round_trip(tmp_path):
+    from pti_ldm_vae_amd.models import PerceptualLoss, SqueezeLPIPS
+    torch.manual_seed(0)
+    src = SqueezeLPIPS()
+    sd = src.state_dict()
+    backbone = {k: v for k, v in sd.items() if k.startswith("features.")}
+    backbone["classifier.1.weight"] = torch.zeros(1000, 512, 1, 1)            # present in torchvision's file, ignored
+    lin = {k: v.abs() for k, v in sd.items() if k.startswith("lin")}
+    torch.save(backbone, tmp_path / "squeezenet1_1.pth")
+    torch.save(lin, tmp_path / "squeeze.pth")
+    with pytest.raises(RuntimeError, match="not available offline"):
+        PerceptualLoss()
+    loss = PerceptualLoss(weights=(str(tmp_path / "squeezenet1_1.pth"), str(tmp_path / "squeeze.pth")))
+    assert loss.pretrained
+    for k, v in loss.net.state_dict().items():
+        assert torch.equal(v, backbone[k] if k.startswith("features.") else lin[k])
+    del lin["lin3.model.1.weight"]
+    torch.save(lin, tmp_path / "broken.pth")
+    with pytest.raises(KeyError):
+        PerceptualLoss(weights=(str(tmp_path / "squeezenet1_1.pth"), str(tmp_path / "broken.pth")))
+    with pytest.raises(ValueError):
+        PerceptualLoss(spatial_dims=3, allow_random_init=True)
+
+
+def test_lpips_properties():
+    from pti_ldm_vae_amd.models import PerceptualLoss
+    torch.manual_seed(1)
+    loss = PerceptualLoss(allow_random_init=True)
+    with torch.no_grad():
+        for k in range(7):                      # non-negative lin weights, as in the trained LPIPS
+            getattr(loss.net, f"lin{k}").model[1].weight.abs_()
+    a, b = torch.rand(3, 1, 64, 64) * 2 - 1, torch.rand(3, 1, 64, 64) * 2 - 1
+    assert float(loss(a, a)) == 0.0
+    assert float(loss(a, b)) > 0 and float(loss(a, b)) == pytest.approx(float(loss(b, a)), rel=1e-6)
+    per = torch.stack([loss(a[i:i + 1], b[i:i + 1]) for i in range(3)])
+    assert float(loss(a, b)) == pytest.approx(float(per.mean()), rel=1e-5)
+    a3 = a.repeat(1, 3, 1, 1)                   # the reference repeats to three channels itself before the call
+    assert float(loss(a3, b)) == pytest.approx(float(loss(a, b)), rel=1e-6)
+    x = a.clone().requires_grad_(True)
+    loss(x, b).backward()
+    assert x.grad is not None and float(x.grad.abs().sum()) > 0
+
+
+def test_trainer_argument_validation():
+    """perceptual_weight without a module is an error at construction (checked before any GPU work)."""
+    from pti_ldm_vae_amd import trainer
+    import inspect
+    sig = inspect.signature(trainer.VAETrainer.__init__)
+    assert "perceptual" in sig.parameters and "perceptual_weight" in sig.parameters
