@@ -538,6 +538,17 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
 constexpr int W4_STG = 20 * 1024, W4_DP = 3, W4_NSTAGE = 2 * (W4_DP + 1), W4_IMG = 9 * 32 * 32 * 4;   // DP = pairs of tiles ahead
+// "two output-channel blocks per tile" mode (jobs with Cout % 64 == 0): both wave groups work on the SAME pixel tile,
+// group g on output-channel block 2*cot + g.  The x halo (12 KB) is then fetched once for two blocks: a stage is
+// 12 + 2 x 8 = 28 KB for the 144 MFMAs that the pair mode feeds with 2 x 20 = 40 KB.  Ring: five 28-KB stages, four
+// tiles ahead.  Measured (same box, config A batch 32): the >= 64-channel layers 582 -> 619 TFLOP/s, step -1.1 %; AR
+// model 635 -> 678 TFLOP/s.  30 % fewer fill bytes bought 6-7 %: the fill is not the only bound.  What remains is the
+// LDS READ side -- 28 transposing fragment reads (56 ds_read_b64_tr_b16 = 28.7 KB) per wave and tile for 18 MFMAs:
+// 8 waves x 56 x 4 cycles = 1792 LDS cycles per tile pair against 8 x 18 / 4 x 32 = 1152 MFMA cycles per SIMD.  Fewer
+// reads per MFMA need more accumulators per wave (an x fragment is shared by the kernel rows of up to three output rows
+// and by every output-channel block a wave owns): one wave per SIMD with two blocks in 288 registers (0.44 fragments
+// per MFMA instead of 0.78) is the design this points to.
+constexpr int W4_STG2 = 28 * 1024, W4_DP2 = 4, W4_NST2 = W4_DP2 + 1;
 constexpr int W4_LDS = (W4_NSTAGE * W4_STG > 4 * W4_IMG + 1024) ? W4_NSTAGE * W4_STG : 4 * W4_IMG + 1024;
 
 // Up to PTI_WGRAD_BATCH_MAX independent weight-gradient problems in ONE launch (+ one slab-reduction launch): a launch
@@ -547,6 +558,7 @@ struct W4Job {
   const bf16* x; const bf16* dy; float* slab;
   long long slab_stride;
   int N, H, W, Cin, Cout, tiles_x, tiles_y, ntiles, S;
+  int cob2;   // two output-channel blocks per workgroup (see W4_STG2)
 };
 // Workgroup placement.  The (co, ci) blocks of one pixel split of one job stream the SAME x / dy tiles, so they must
 // share an XCD (one L2 per XCD; workgroup ids are dealt round-robin over the 8 XCDs: id & 7 names the XCD -- for speed
@@ -555,22 +567,29 @@ struct W4Job {
 // (job, split, block) from id & 7, id >> 3 and the group list of that XCD.  Measured without it on the batched launch
 // (S = 1..2 per job: consecutive ids = different blocks of one split, spread over all XCDs): 2.1x the algorithmic
 // bytes fetched.
-constexpr int W4_MAXGRP = 32;   // groups per XCD (=> at most 256 groups per launch)
+constexpr int W4_MAXGRP = 64;   // groups per XCD (=> at most 512 groups per launch; the batch struct must stay under the 4-KB kernarg limit)
 struct W4Batch {
   W4Job job[PTI_WGRAD_BATCH_MAX];
   float* dw[PTI_WGRAD_BATCH_MAX];
   float* dbias[PTI_WGRAD_BATCH_MAX];
   int accumulate[PTI_WGRAD_BATCH_MAX];
   int first_rblk[PTI_WGRAD_BATCH_MAX + 1];   // blocks of the reduction launch
-  unsigned grp[8][W4_MAXGRP];                 // job | split << 8
+  unsigned short grp[8][W4_MAXGRP];           // job (4 bits) | split << 4
   unsigned short grp_start[8][W4_MAXGRP + 1]; // first position (id >> 3) of each group in its XCD's list
   int ngrp[8];
   int njobs, diag, nwg;
 };
 
+static_assert(sizeof(W4Batch) <= 4096 && PTI_WGRAD_BATCH_MAX <= 16, "kernarg limit / 4-bit job index of the group word");
+
+// COB2: every job of the batch runs in the two-output-channel-block mode (see W4_STG2) -- a compile-time switch: with
+// the mode as a run-time (block-uniform) flag the shared hot loop carried both address schemes and ran 20 % slower
+// in either mode (same-box: 660 -> 798 us per launch).  A batch never mixes modes; the host splits the jobs.
+template <bool COB2>
 __global__ __launch_bounds__(512, 1) void wgrad_mfma4_kernel(W4Batch b) {
   constexpr int HWp = TW + 2, NPX = 10 * HWp, PP = 64, XB = 12 * 1024, STG = W4_STG, DP = W4_DP, NPS = DP + 1;   // NPS pair slots
   static_assert(W4_LDS <= 160 * 1024 && 5 * (DP - 1) <= 63, "ring must fit the LDS and the vmcnt counter");
+  static_assert(W4_NST2 * W4_STG2 <= W4_LDS && 5 * (W4_DP2 - 1) <= 63, "two-block ring must fit as well");
   // ---- which (job, pixel split, (co,ci) block) is this workgroup? (block-uniform scalar code) ----
   const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
   const int ng = b.ngrp[xcd];
@@ -578,7 +597,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_mfma4_kernel(W4Batch b) {
   int gi = 0;
   while (gi + 1 < ng && pos >= b.grp_start[xcd][gi + 1]) ++gi;
   const unsigned gword = b.grp[xcd][gi];
-  const int jb = gword & 255, split = gword >> 8, cc = pos - b.grp_start[xcd][gi];
+  const int jb = gword & 15, split = gword >> 4, cc = pos - b.grp_start[xcd][gi];
   const W4Job& a = b.job[jb];
   const int ci_tiles = a.Cin / 32;
   typedef short v4s __attribute__((ext_vector_type(4)));
@@ -589,7 +608,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_mfma4_kernel(W4Batch b) {
   const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = w8 >> 2, w = w8 & 3;
   const int cot = cc / ci_tiles, cit = cc % ci_tiles;
-  const int co0 = cot * 32, ci0 = cit * 32;
+  constexpr bool cob2 = COB2;
+  const int co0 = cob2 ? (2 * cot + grp) * 32 : cot * 32, ci0 = cit * 32;   // (wave-uniform in the two-block mode)
   const bool do_bias = (cit == 0);   // block-uniform
 
   // ---- DMA slots of this lane: 3 x pieces (instructions w, w+4, w+8 of the stage) and 2 dy pieces (w, w+4) ----
@@ -631,7 +651,9 @@ __global__ __launch_bounds__(512, 1) void wgrad_mfma4_kernel(W4Batch b) {
   };
   auto issue_slot = [&](const TilePos& tp, int stage, int k) {   // k is a compile-time constant at every call site
     if (b.diag & 1) return;                                   // tuning aid: no tile loads
-    const unsigned sbase = lds0 + stage * STG + w * 1024;
+    // two-block mode: ONE stage per tile; group 0 fetches the x halo and its dy block, group 1 only its dy block
+    if (cob2 && k < 3 && grp == 1) return;
+    const unsigned sbase = lds0 + (cob2 ? stage * W4_STG2 + (k >= 3 ? grp * 8192 : 0) : stage * STG) + w * 1024;
     if (k < 3) {
       bool ok = tp.live && xhy[k] < 16;
       if (!tp.interior) {
@@ -670,15 +692,21 @@ __global__ __launch_bounds__(512, 1) void wgrad_mfma4_kernel(W4Batch b) {
   // tiles of this split: split, split + S, ...; iteration `it` handles the pair (2 it, 2 it + 1), group g its element g
   const int ntl = a.ntiles > split ? (a.ntiles - split + a.S - 1) / a.S : 0;
   const int npair = (ntl + 1) >> 1;
+  if (cob2) {
+    // ---- one tile per iteration, shared by the two groups ----
+#pragma unroll
+    for (int s = 0; s < W4_DP2; ++s) issue(split + s * a.S, s);
+  } else {
 #pragma unroll
   for (int s = 0; s < DP; ++s) issue(split + (2 * s + grp) * a.S, 2 * s + grp);
+  }
   // compute(pslot, ft, fstage): 18 (+2) MFMAs of this wave's two output rows of its group's tile in pair slot `pslot`;
   // this wave's five DMA pieces of the future tile `ft` are issued BETWEEN the MFMA groups (one after each halo
   // row, one at the end) instead of in front of them: a wave that queues behind a full memory pipe at a DMA
   // instruction then has MFMAs in flight, and its SIMD partner keeps the matrix pipe busy meanwhile.
   auto compute = [&](int pslot, const TilePos& ft, int fstage) {
-    const unsigned char* lA = smem + (2 * pslot + grp) * STG;
-    const unsigned char* lD = lA + XB;
+    const unsigned char* lA = cob2 ? smem + pslot * W4_STG2 : smem + (2 * pslot + grp) * STG;
+    const unsigned char* lD = lA + XB + (cob2 ? grp * 8192 : 0);
     bf16x8 dfr[2];
 #pragma unroll
     for (int oi = 0; oi < 2; ++oi) {
@@ -711,22 +739,31 @@ __global__ __launch_bounds__(512, 1) void wgrad_mfma4_kernel(W4Batch b) {
     }
     issue_slot(ft, fstage, 4);
   };
-  int ps = 0;                                   // pair slot of iteration `it`
-  for (int it = 0; it < npair; ++it) {
-    int fs = ps + DP;
-    fs = fs >= NPS ? fs - NPS : fs;
-    const int kf = 2 * (it + DP) + grp;
+  // ONE loop (and one inlined copy of compute(): a second call site doubled the live ranges and spilled) for both
+  // modes: pair mode -- slot = pair slot, NPS slots, DP pairs ahead, group g owns stage 2*slot + g and tile 2*it + g;
+  // two-block mode -- slot = stage, W4_NST2 stages, W4_DP2 tiles ahead, both groups share tile `it`.
+  const int nit = cob2 ? ntl : npair, nslot = cob2 ? W4_NST2 : NPS, ahead = cob2 ? W4_DP2 : DP;
+  int ps = 0;                                   // ring slot of iteration `it`
+  for (int it = 0; it < nit; ++it) {
+    int fs = ps + ahead;
+    fs = fs >= nslot ? fs - nslot : fs;
+    const int kf = cob2 ? it + ahead : 2 * (it + ahead) + grp;
     const TilePos ft = locate(kf < ntl ? split + kf * a.S : a.ntiles);
-    wait_vmcnt<5 * (DP - 1)>();           // this wave's 5 pieces of pair `it` have landed (younger pairs may fly)
+    // this wave's pieces of iteration `it` have landed (younger iterations may fly): 5 DMA instructions per wave and
+    // iteration, except group 1 in the two-block mode (its two dy instructions only)
+    if (!cob2) wait_vmcnt<5 * (DP - 1)>();
+    else if (grp == 0) wait_vmcnt<5 * (W4_DP2 - 1)>();
+    else wait_vmcnt<2 * (W4_DP2 - 1)>();
     __builtin_amdgcn_s_barrier();         // ... everyone's have, and everyone is done reading the slot refilled below
     // (the second tile of an odd last pair is a tile past the end: all zeros, it adds nothing)
+    const int fstage = cob2 ? fs : 2 * fs + grp;
     if (b.diag & 2) {                     // tuning aid: loads only
 #pragma unroll
-      for (int k = 0; k < 5; ++k) issue_slot(ft, 2 * fs + grp, k);
+      for (int k = 0; k < 5; ++k) issue_slot(ft, fstage, k);
     } else {
-      compute(ps, ft, 2 * fs + grp);
+      compute(ps, ft, fstage);
     }
-    ps = ps + 1 == NPS ? 0 : ps + 1;
+    ps = ps + 1 == nslot ? 0 : ps + 1;
   }
   wait_vmcnt<0>();                        // the zero-page pieces of the tiles past the end
   __syncthreads();                        // every wave is done with the ring: it becomes the reduction scratch
@@ -767,6 +804,34 @@ __global__ __launch_bounds__(512, 1) void wgrad_mfma4_kernel(W4Batch b) {
     for (int r = 0; r < 16; ++r) bred[w8 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel] = accb[r];
   }
   if (b.diag & 8) return;
+  if (cob2) {
+    // the four waves of a group hold partial sums of ONE block (group g: output-channel block 2*cot + g) over different
+    // pixel rows: waves 2,3 -> images, waves 0,1 add; wave 1 -> image, wave 0 adds and leaves the total in image g
+    if (w >= 2) dump(red + (2 * grp + w - 2) * 9216);
+    __syncthreads();
+    if (w < 2) gather(red + (2 * grp + w) * 9216);
+    __syncthreads();
+    if (w == 1) dump(red + grp * 9216);
+    __syncthreads();
+    if (w == 0) gather(red + grp * 9216);
+    __syncthreads();
+    if (w == 0) dump(red + grp * 9216);
+    __syncthreads();
+    // blocks (2*cot, cit) and (2*cot + 1, cit) of the 32 x 32 block grid: ci_tiles blocks apart in the slab
+    float* slab2 = a.slab + (size_t)split * a.slab_stride + (size_t)(2 * cot * ci_tiles + cit) * 9216;
+    for (int i4 = tid; i4 < 2 * 2304; i4 += 512) {
+      const int g2 = i4 >= 2304, j4 = i4 - g2 * 2304;
+      *(f32x4*)(slab2 + (size_t)g2 * ci_tiles * 9216 + j4 * 4) = *(const f32x4*)(red + g2 * 9216 + j4 * 4);
+    }
+    if (do_bias && tid < 64) {
+      const int g2 = tid >> 5;
+      float sm = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) sm += bred[(g2 * 4 + k) * 32 + (tid & 31)];
+      a.slab[(size_t)split * a.slab_stride + (size_t)9 * a.Cout * a.Cin + cot * 64 + tid] = sm;
+    }
+    return;
+  }
   if (!(b.diag & 4)) {
     if (w8 >= 4) dump(red + (w8 - 4) * 9216);
     __syncthreads();
@@ -905,6 +970,8 @@ static void w4_fill_job(W4Job& a, const void* x, const void* dy, int n, int h, i
   a.tiles_x = cdiv(w, TW); a.tiles_y = cdiv(h, TH); a.ntiles = n * a.tiles_x * a.tiles_y;
   a.slab_stride = (long long)9 * cout * cin + cout;
   a.S = 1;
+  static const int cob2_env = getenv("PTI_WGRAD_V4_COB2") ? atoi(getenv("PTI_WGRAD_V4_COB2")) : 1;
+  a.cob2 = (cob2_env && cout % 64 == 0) ? 1 : 0;
 }
 static bool w4_eligible(int n, int h, int w, int cin, int cout) {
   return n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && cin % 32 == 0 && cout % 32 == 0 &&
@@ -920,9 +987,10 @@ static long long w4_plan(W4Batch& b, float* workspace, long long workspace_float
   static const int wgs_env = getenv("PTI_WGRAD_V4_WGS") ? atoi(getenv("PTI_WGRAD_V4_WGS")) : 2048;
   static const int diag_env = getenv("PTI_WGRAD_V4_DIAG") ? atoi(getenv("PTI_WGRAD_V4_DIAG")) : 0;
   b.diag = diag_env;
-  auto tiles32 = [](const W4Job& a) { return (a.Cin / 32) * (a.Cout / 32); };
-  double work = 0;   // workgroup-tiles of the whole launch
-  for (int j = 0; j < b.njobs; ++j) work += (double)tiles32(b.job[j]) * b.job[j].ntiles;
+  // workgroups of one pixel split: (co, ci) blocks of 32 x 32, or of 64 x 32 in the two-block mode
+  auto tiles32 = [](const W4Job& a) { return (a.Cin / 32) * (a.Cout / (a.cob2 ? 64 : 32)); };
+  double work = 0;   // 32 x 32-block tiles of the whole launch (a two-block workgroup does two per pixel tile)
+  for (int j = 0; j < b.njobs; ++j) work += (double)tiles32(b.job[j]) * (b.job[j].cob2 ? 2 : 1) * b.job[j].ntiles;
   double per_wg = work / wgs_env > 2.0 ? work / wgs_env : 2.0;   // tiles per workgroup aimed at (at least one pair)
   for (int attempt = 0;; ++attempt) {
     long long used = 0;
@@ -930,8 +998,10 @@ static long long w4_plan(W4Batch& b, float* workspace, long long workspace_float
     bool fits = true;
     for (int j = 0; j < b.njobs; ++j) {
       W4Job& a = b.job[j];
-      int S = (int)((double)a.ntiles / per_wg + 0.5);
-      if (S > a.ntiles / 2) S = a.ntiles / 2;
+      // per_wg = pixel tiles per workgroup in the pair mode (two per iteration); a two-block workgroup takes one pixel
+      // tile per iteration, so the same running time is per_wg / 2 pixel tiles: twice the splits
+      int S = (int)((double)a.ntiles * (a.cob2 ? 2 : 1) / per_wg + 0.5);
+      if (S > a.ntiles / (a.cob2 ? 1 : 2)) S = a.ntiles / (a.cob2 ? 1 : 2);
       if (S > 255) S = 255;
       if (S < 1) S = 1;
       if (used + (long long)S * a.slab_stride > workspace_floats) fits = false;
@@ -960,7 +1030,7 @@ static long long w4_plan(W4Batch& b, float* workspace, long long workspace_float
           for (int x = 1; x < 8; ++x)
             if (len[x] < len[best]) best = x;
           if (b.ngrp[best] >= W4_MAXGRP || len[best] + tiles32(b.job[j]) > 65535) { ok = false; break; }
-          b.grp[best][b.ngrp[best]] = (unsigned)j | ((unsigned)sp << 8);
+          b.grp[best][b.ngrp[best]] = (unsigned short)((unsigned)j | ((unsigned)sp << 4));
           len[best] += tiles32(b.job[j]);
           b.grp_start[best][++b.ngrp[best]] = (unsigned short)len[best];
         }
@@ -1054,7 +1124,8 @@ extern "C" int pti_conv_wgrad_mfma_partials(const void* x, const void* dy, const
     b.accumulate[0] = 0;
     if (w4_plan(b, (float*)workspace, workspace_bytes / 4) < 0)
       PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma: workspace too small (%lld bytes per split needed)", a.slab_stride * 4);
-    PTI_LAUNCH(wgrad_mfma4_kernel, dim3(b.nwg), dim3(512), 0, (hipStream_t)s, b);
+    if (b.job[0].cob2) PTI_LAUNCH(wgrad_mfma4_kernel<true>, dim3(b.nwg), dim3(512), 0, (hipStream_t)s, b);
+    else PTI_LAUNCH(wgrad_mfma4_kernel<false>, dim3(b.nwg), dim3(512), 0, (hipStream_t)s, b);
     PTI_CHECK_LAUNCH("conv_wgrad_mfma");
     *splits_out = b.job[0].S | PTI_WGRAD_SLAB_V4;   // the reduction must know the slab layout
     return PTI_OK;
@@ -1112,22 +1183,41 @@ extern "C" int pti_conv_wgrad_mfma_batched(const pti_wgrad_job* jobs, int njobs,
                                            pti_stream_t s) {
   if (!jobs || !workspace || njobs < 1 || njobs > PTI_WGRAD_BATCH_MAX)
     PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma_batched: 1..%d jobs", PTI_WGRAD_BATCH_MAX);
-  W4Batch b;
-  b.njobs = njobs;
+  // two batches, one per kernel mode (two output-channel blocks per workgroup for Cout % 64 == 0, pairs of tiles
+  // otherwise); each gets its own launch pair and its own part of the workspace
+  W4Batch bm[2];
+  bm[0].njobs = bm[1].njobs = 0;
   for (int j = 0; j < njobs; ++j) {
     const pti_wgrad_job& q = jobs[j];
     if (!q.x || !q.dy || !q.dw) PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma_batched: job %d has a null pointer", j);
     if (!w4_eligible(q.n, q.h, q.w, q.cin, q.cout))
       PTI_FAIL(PTI_EUNSUPPORTED, "conv_wgrad_mfma_batched: job %d: n=%d h=%d w=%d cin=%d cout=%d (channels must be multiples of 32, tensors < 2 GiB)",
                j, q.n, q.h, q.w, q.cin, q.cout);
-    w4_fill_job(b.job[j], q.x, q.dy, q.n, q.h, q.w, q.cin, q.cout);
-    b.dw[j] = q.dw; b.dbias[j] = q.dbias; b.accumulate[j] = q.accumulate;
+    W4Job jb;
+    w4_fill_job(jb, q.x, q.dy, q.n, q.h, q.w, q.cin, q.cout);
+    W4Batch& b = bm[jb.cob2 ? 1 : 0];
+    const int k = b.njobs++;
+    b.job[k] = jb;
+    b.dw[k] = q.dw; b.dbias[k] = q.dbias; b.accumulate[k] = q.accumulate;
   }
-  if (w4_plan(b, (float*)workspace, workspace_bytes / 4) < 0) PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma_batched: workspace too small");
-  PTI_LAUNCH(wgrad_mfma4_kernel, dim3(b.nwg), dim3(512), 0, (hipStream_t)s, b);
-  PTI_CHECK_LAUNCH("conv_wgrad_mfma_batched");
-  PTI_LAUNCH(wgrad_reduce4_kernel, dim3(b.first_rblk[njobs]), dim3(256), 0, (hipStream_t)s, b);
-  PTI_CHECK_LAUNCH("conv_wgrad_mfma_batched reduce");
-  pti_last_kernel = reinterpret_cast<const void*>(wgrad_mfma4_kernel);   // pti_last_kernel_name(): the call's main kernel
+  float* ws = (float*)workspace;
+  long long ws_floats = workspace_bytes / 4;
+  for (int m = 1; m >= 0; --m) {      // the two-block batch first (it is the larger one on every model of the reference)
+    W4Batch& b = bm[m];
+    if (b.njobs == 0) continue;
+    // when both modes are present the first batch may take at most 3/4 of the workspace
+    const long long avail = (m == 1 && bm[0].njobs > 0) ? ws_floats * 3 / 4 : ws_floats;
+    const long long used = w4_plan(b, ws, avail);
+    if (used < 0) PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma_batched: workspace too small");
+    ws += used;
+    ws_floats -= used;
+    if (m == 1) PTI_LAUNCH(wgrad_mfma4_kernel<true>, dim3(b.nwg), dim3(512), 0, (hipStream_t)s, b);
+    else PTI_LAUNCH(wgrad_mfma4_kernel<false>, dim3(b.nwg), dim3(512), 0, (hipStream_t)s, b);
+    PTI_CHECK_LAUNCH("conv_wgrad_mfma_batched");
+    PTI_LAUNCH(wgrad_reduce4_kernel, dim3(b.first_rblk[b.njobs]), dim3(256), 0, (hipStream_t)s, b);
+    PTI_CHECK_LAUNCH("conv_wgrad_mfma_batched reduce");
+  }
+  // pti_last_kernel_name(): the call's main kernel
+  pti_last_kernel = bm[1].njobs ? reinterpret_cast<const void*>(wgrad_mfma4_kernel<true>) : reinterpret_cast<const void*>(wgrad_mfma4_kernel<false>);
   return PTI_OK;
 }
