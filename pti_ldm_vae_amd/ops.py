@@ -328,14 +328,31 @@ def conv_wgrad_mfma_batched(jobs, workspace=None, accumulate=True):
         nbytes += 2.0 * (x.numel() + dy.numel())
     ws = workspace if workspace is not None else wgrad_workspace(jobs[0][0].device)
     prof = KERNEL_PROFILE
-    if prof is not None:
+    if prof is None:
+        L.check(L.lib().pti_conv_wgrad_mfma_batched(arr, len(jobs), _ptr(ws), ws.numel() * 4, _stream()),
+                "pti_conv_wgrad_mfma_batched")
+        return
+    # profiling: the library launches one kernel per mode (two output-channel blocks per workgroup for Cout % 64 == 0,
+    # tile pairs otherwise); issue the two groups as two calls so that each kernel gets its own record (its own
+    # algorithmic work, its own duration = partial launch + the <1 % reduction launch) under its own name
+    cob2 = os.environ.get("PTI_WGRAD_V4_COB2", "1") != "0"
+    groups = {}
+    for i, (x, dy, dw, db) in enumerate(jobs):
+        groups.setdefault(bool(cob2 and dy.shape[3] % 64 == 0), []).append(i)
+    for mode in (True, False):
+        idx = groups.get(mode)
+        if not idx:
+            continue
+        sub = (L.WgradJob * len(idx))(*[arr[i] for i in idx])
+        fl = sum(2.0 * jobs[i][0].shape[0] * jobs[i][0].shape[1] * jobs[i][0].shape[2] * jobs[i][1].shape[3] * jobs[i][0].shape[3] * 9
+                 for i in idx)
+        nb = sum(2.0 * (jobs[i][0].numel() + jobs[i][1].numel()) for i in idx)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    L.check(L.lib().pti_conv_wgrad_mfma_batched(arr, len(jobs), _ptr(ws), ws.numel() * 4, _stream()),
-            "pti_conv_wgrad_mfma_batched")
-    if prof is not None:   # the partial launch + the (<1 % of the time) reduction launch of the whole batch
+        L.check(L.lib().pti_conv_wgrad_mfma_batched(sub, len(idx), _ptr(ws), ws.numel() * 4, _stream()),
+                "pti_conv_wgrad_mfma_batched")
         e1.record()
-        prof.append((last_kernel_name(), flops, nbytes, e0, e1, ("conv wgrad (batched)", 0, 0, 0, 0, 3, "s1", len(jobs))))
+        prof.append((last_kernel_name(), fl, nb, e0, e1, ("conv wgrad (batched)", 0, 0, 0, 0, 3, "s1", len(idx))))
 
 
 def gn_bwd(x, da, dx, stats, gamma, beta, sums, dgamma, dbeta, *, groups, eps=1e-6, silu=True, dres=None):
