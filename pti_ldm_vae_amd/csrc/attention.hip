@@ -4,7 +4,10 @@
 // backward, which recomputes the probabilities).  bf16 MFMA 32x32x16, fp32 softmax / accumulate.
 //
 // Data: qkv [B, L, 3C] bf16 (output of the fused to_q/to_k/to_v 1x1 conv), o / do [B, L, C] bf16.
-// One workgroup = 2 waves = 64 tokens (32 per wave) of one image; token tiles of 64 (32 for C=256)
+// One workgroup = 4 waves = 128 tokens (32 per wave) of one image (two waves until late round 2: a streamed K/V tile then
+// fed half as many MFMAs, and at head dim 256 the per-CU L2 -> LDS fill -- 76 KB per 32 keys -- outran the MFMAs 3:1;
+// with four waves sharing a tile: dk/dv 867 -> 774 us, dq 438 -> 380, fwd 392 -> 356 at L = 4096, batch 8; head dim 128,
+// L = 1024, batch 32: 181 -> 110, 99 -> 81, 60 -> 53 us); token tiles of 64 (32 for C=256)
 // are staged in LDS as plain [token][d] rows with pitch 2*D+80 bytes (conflict-free ds_read_b128,
 // near conflict-free ds_read_b64_tr_b16).
 //
@@ -20,7 +23,7 @@ namespace {
 typedef short v4s __attribute__((ext_vector_type(4)));
 typedef short v8s __attribute__((ext_vector_type(8)));
 
-constexpr int NW = 2;          // waves per workgroup
+constexpr int NW = 4;          // waves per workgroup
 constexpr int TB = 32 * NW;    // tokens owned by a workgroup
 
 template <int D>
@@ -170,10 +173,15 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const bf16* __restric
         ps += p;
       }
     lsum = lsum * alpha + ps;
+    // rescale the output accumulators only when some query of this wave saw a new maximum in this tile (alpha == 1
+    // exactly otherwise: same bits).  After the first few key tiles that is rare, and the rescale -- D/2 multiplies per
+    // lane, through AGPR copies at head dim 256 -- costs more issue slots than the tile's MFMAs.
+    if (__any(alpha != 1.0f)) {
 #pragma unroll
-    for (int d = 0; d < C::DB; ++d)
+      for (int d = 0; d < C::DB; ++d)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+        for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+    }
 #pragma unroll
     for (int kb = 0; kb < C::NB; ++kb)
 #pragma unroll
