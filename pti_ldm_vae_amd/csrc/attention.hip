@@ -320,7 +320,9 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const bf16* __rest
 
 // ------------------------------------------------------------------------------------------------
 // dK, dV: workgroup owns 64 keys, streams query tiles.  P[query][key] (key on the lane):
-// dV^T[d][key] += dO^T P,  dK^T[d][key] += Q^T dS.  DSPLIT splits d over blockIdx.z to bound VGPRs.
+// dV^T[d][key] += dO^T P,  dK^T[d][key] += Q^T dS.  DSPLIT splits d over blockIdx.z to bound VGPRs (no longer used: with
+// four waves per workgroup the streamed-tile staging registers halved and head dim 256 fits unsplit -- 512 registers and
+// 40 spilled -- which drops the second computation of S and dP and the second pass over Q/dO: 774 -> 529 us).
 template <int D, int DSPLIT>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_dkdv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
                                                                 const float* __restrict__ lse2,
@@ -463,7 +465,7 @@ extern "C" int pti_attention_bwd(const void* qkv, const void* o, const void* dou
     PTI_LAUNCH((attn_bwd_dkdv_kernel<128, 1>), grid, blk, 0, st, Q, DO, lse2, delta, DQ, l, c_log2, scale);
   } else {
     PTI_LAUNCH(attn_bwd_dq_kernel<256>, grid, blk, 0, st, Q, DO, lse2, delta, DQ, l, c_log2, scale);
-    PTI_LAUNCH((attn_bwd_dkdv_kernel<256, 2>), dim3((l + TB - 1) / TB, b, 2), blk, 0, st, Q, DO, lse2, delta, DQ, l, c_log2, scale);
+    PTI_LAUNCH((attn_bwd_dkdv_kernel<256, 1>), dim3((l + TB - 1) / TB, b, 1), blk, 0, st, Q, DO, lse2, delta, DQ, l, c_log2, scale);
   }
   PTI_CHECK_LAUNCH("attention_bwd");
   return PTI_OK;
