@@ -23,7 +23,16 @@ STAT_SCALE = 65536.0   # GroupNorm statistics are Q47.16 fixed-point int64 {sum,
 ACT16 = (BF16, F16)   # storage formats of a forward activation (flag derived from the tensor's dtype)
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream() -> int:
+    """hipStream_t of torch's current stream on the current device.  The public route (torch.cuda.current_stream()
+    builds a Stream object, resolves the device index through several Python layers) cost ~8 us per call x ~280 calls
+    per training step = a quarter of the step's host time; the two C entry points behind it cost ~0.3 us."""
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 
