@@ -298,3 +298,45 @@ def test_native_trainer_step_vs_oracle_full_size_image(dev):
     assert out["kl"].item() == pytest.approx(kl_o.item(), rel=1e-3)
     assert cos_g >= 0.999 and abs((g_h.norm() / g_o.norm()).item() - 1.0) <= 1e-2
     assert cos_d >= 0.99 and cos_d_big >= 0.999
+
+
+def test_twenty_step_training_trajectory_vs_oracle(dev):
+    """Twenty optimiser steps of the native trainer against twenty steps of the oracle (fp32 CPU forward + autograd +
+    torch.optim.Adam) from the same weights, on the same two batches alternating, with the same injected eps per step:
+    the LOSS TRAJECTORY must track (each step within 3 %: single-step parity is 4e-5, but Adam's early updates are
+    lr * sign(g), so parameters whose gradient sits at the 16-bit noise floor take different +-lr steps and the two
+    runs drift apart chaotically; measured: 0.6214 -> 0.3903 (oracle) vs 0.6213 -> 0.3912, worst step 1.2 %) and the
+    accumulated parameter displacement must point the same way (cosine >= 0.98 over all 4.56 M parameters, measured 0.995;
+    norm ratio within 3 %, measured 1.0013)."""
+    from oracle.autoencoderkl import CONFIG_A
+    from oracle.losses import train_step_losses
+    from pti_ldm_vae_amd.trainer import VAETrainer
+    torch.set_num_threads(16)
+    oracle, model = _build(CONFIG_A, dev)
+    xa, _ = _inputs(CONFIG_A, 2, 64, seed=11)
+    xb, _ = _inputs(CONFIG_A, 2, 64, seed=12)
+    lat = 64 // (2 ** (len(CONFIG_A["channels"]) - 1))
+    eps = torch.randn(20, 2, CONFIG_A["latent_channels"], lat, lat, generator=torch.Generator().manual_seed(13))
+    lr = 2e-4
+    p0 = torch.cat([p.detach().flatten() for p in oracle.parameters()])
+    opt = torch.optim.Adam(oracle.parameters(), lr=lr)
+    tr = VAETrainer(model, lr=lr)
+    lo, lh = [], []
+    for i in range(20):
+        x = xa if i % 2 == 0 else xb
+        opt.zero_grad(set_to_none=True)
+        loss_o, _, _, _ = train_step_losses(oracle, x, eps[i])
+        loss_o.backward()
+        opt.step()
+        lo.append(float(loss_o))
+        lh.append(tr.step(x.to(dev), eps[i].to(dev))["loss"])
+    lh = [float(v) for v in lh]
+    d_o = torch.cat([p.detach().flatten() for p in oracle.parameters()]) - p0
+    ae = model.autoencoder
+    d_h = torch.cat([p.detach().cpu().flatten() for _, p in ae.named_parameters()]) - p0
+    worst = max(abs(a - b) / abs(b) for a, b in zip(lh, lo))
+    print(f"[20-step trajectory] loss {lo[0]:.4f} -> {lo[-1]:.4f} (oracle), {lh[0]:.4f} -> {lh[-1]:.4f} (HIP); worst step "
+          f"deviation {worst:.2e}; displacement cosine {_cos(d_h, d_o):.4f}, norm ratio {(d_h.norm() / d_o.norm()).item():.4f}")
+    assert lo[-1] < lo[0] and lh[-1] < lh[0]
+    assert worst <= 3e-2
+    assert _cos(d_h, d_o) >= 0.98 and abs((d_h.norm() / d_o.norm()).item() - 1.0) <= 0.03
