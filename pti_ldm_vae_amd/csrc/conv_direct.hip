@@ -35,40 +35,80 @@ __device__ __forceinline__ void st_narrow(void* p, long long idx, int f32, float
   else ((bf16*)p)[idx] = (bf16)v;
 }
 
-// ---- few input channels -> many output channels (cout % 32 == 0, output NHWC bf16 dense) ----
-// thread = (pixel, 32-cout block = blockIdx.y); weights are block-uniform (scalar loads).
+// ---- few input channels -> many output channels (cout % 32 == 0, output NHWC 16-bit dense) ----
+// thread = (pixel, 8-channel octet of the 32-cout block blockIdx.y): FOUR consecutive lanes own one pixel's 64 bytes,
+// so a wave's store instruction writes 1 KiB of consecutive addresses.  (The first version gave a thread the whole
+// 32-channel row of its pixel: four 16-byte stores per lane at a 64-byte lane stride = 64 partial-line requests per
+// instruction -- conv_in 1 -> 32 at 256^2, batch 32, a 134-MB write, ran at 1.3 TB/s: 103 us.)  The narrow input and
+// the weights are re-read by the four lanes of a pixel (same address: one request).
 __global__ __launch_bounds__(256) void direct_fewcin_kernel(DArgs a) {
   if (a.wide_f16) fp16_saturate_on();   // wave-uniform: fp16 output saturates instead of overflowing to inf
-  const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
-  const long long npix = (long long)a.N * a.H * a.W;
-  if (pix >= npix) return;
-  const int ox = pix % a.W;
-  const int oy = (pix / a.W) % a.H;
-  const int n = pix / ((long long)a.W * a.H);
-  const int cb = blockIdx.y * 32;
+  // 32-bit index arithmetic (the host checks n*h*w*4 < 2^31): the 64-bit divisions of the first version cost several
+  // hundred instructions per thread -- more than the convolution itself
+  const unsigned gid = blockIdx.x * 256u + threadIdx.x;
+  const int c8 = (int)(gid & 3);
+  const unsigned npix = (unsigned)a.N * a.H * a.W;
+  const int cb = blockIdx.y * 32 + c8 * 8;
   const int pad = (a.KS - 1) / 2;
-  float acc[32];
+  const bool one = a.Cin == 1 && a.KS == 3;
+  // one input channel (conv_in of a grey-scale model and its mirror, the data gradient of conv_out): the 9 x 8 weights
+  // of this lane live in registers, the loop is 9 loads + 72 FMAs (with the weights re-read per tap: 27 loads)
+  f32x2 wr[9][4];   // pairs: the FMAs below are packed (v_pk_fma_f32, two channels per instruction)
+  if (one) {
 #pragma unroll
-  for (int c = 0; c < 32; ++c) acc[c] = a.bias ? a.bias[cb + c] : 0.f;
-  for (int kh = 0; kh < a.KS; ++kh) {
-    const int iy = oy + kh - pad;
-    if (iy < 0 || iy >= a.H) continue;
-    for (int kw = 0; kw < a.KS; ++kw) {
-      const int ix = ox + kw - pad;
-      if (ix < 0 || ix >= a.W) continue;
-      const long long ibase = n * a.is[0] + iy * a.is[1] + ix * a.is[2];
-      const float* wt = a.w + (size_t)((kh * a.KS + kw) * a.Cin) * a.Cout + cb;
-      for (int ci = 0; ci < a.Cin; ++ci) {
-        const float v = ld_narrow(a.x, ibase + ci * a.is[3], a.in_f32);
-        const float* wr = wt + (size_t)ci * a.Cout;
-#pragma unroll
-        for (int c = 0; c < 32; ++c) acc[c] += v * wr[c];
-      }
+    for (int t = 0; t < 9; ++t) {
+      const f32x4 w0 = *(const f32x4*)(a.w + (size_t)t * a.Cout + cb), w1 = *(const f32x4*)(a.w + (size_t)t * a.Cout + cb + 4);
+      wr[t][0] = f32x2{w0[0], w0[1]}; wr[t][1] = f32x2{w0[2], w0[3]};
+      wr[t][2] = f32x2{w1[0], w1[1]}; wr[t][3] = f32x2{w1[2], w1[3]};
     }
   }
-  bf16* yo = (bf16*)a.y + (size_t)pix * a.Cout + cb;
+  float b8[8];
 #pragma unroll
-  for (int c = 0; c < 32; c += 8) *(u32x4*)(yo + c) = pack8f(acc + c, a.wide_f16);
+  for (int c = 0; c < 8; ++c) b8[c] = a.bias ? a.bias[cb + c] : 0.f;
+  // persistent threads (grid-stride over the pixels): a workgroup per 64 pixels was 32768 workgroups of ~150
+  // instructions each at 256^2 x 32 -- bound by the dispatch rate, not by its 134-MB write
+  for (unsigned pix = gid >> 2; pix < npix; pix += gridDim.x * 64u) {
+    const unsigned row = pix / (unsigned)a.W;
+    const int ox = (int)(pix - row * a.W);
+    const int n = (int)(row / (unsigned)a.H);
+    const int oy = (int)(row - (unsigned)n * a.H);
+    float acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = b8[c];
+    if (one) {
+      const long long nb = n * a.is[0];
+      f32x2 a2[4] = {f32x2{acc[0], acc[1]}, f32x2{acc[2], acc[3]}, f32x2{acc[4], acc[5]}, f32x2{acc[6], acc[7]}};
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
+        float v = 0.f;
+        if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) v = ld_narrow(a.x, nb + iy * a.is[1] + ix * a.is[2], a.in_f32);
+        const f32x2 vv = {v, v};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a2[c] += vv * wr[t][c];
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { acc[2 * c] = a2[c][0]; acc[2 * c + 1] = a2[c][1]; }
+    } else {
+      for (int kh = 0; kh < a.KS; ++kh) {
+        const int iy = oy + kh - pad;
+        if (iy < 0 || iy >= a.H) continue;
+        for (int kw = 0; kw < a.KS; ++kw) {
+          const int ix = ox + kw - pad;
+          if (ix < 0 || ix >= a.W) continue;
+          const long long ibase = n * a.is[0] + iy * a.is[1] + ix * a.is[2];
+          const float* wt = a.w + (size_t)((kh * a.KS + kw) * a.Cin) * a.Cout + cb;
+          for (int ci = 0; ci < a.Cin; ++ci) {
+            const float v = ld_narrow(a.x, ibase + ci * a.is[3], a.in_f32);
+            const f32x4 w0 = *(const f32x4*)(wt + (size_t)ci * a.Cout), w1 = *(const f32x4*)(wt + (size_t)ci * a.Cout + 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { acc[c] += v * w0[c]; acc[4 + c] += v * w1[c]; }
+          }
+        }
+      }
+    }
+    *(u32x4*)((bf16*)a.y + (size_t)pix * a.Cout + cb) = pack8f(acc, a.wide_f16);
+  }
 }
 
 // ---- many input channels (NHWC 16-bit dense, cin % 8 == 0, cin/8 | 64) -> few output channels ----
@@ -489,7 +529,11 @@ extern "C" int pti_conv2d_direct(const void* x, const float* w, const float* bia
     if (d->prologue) PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_direct: prologue on the narrow input");
     if (d->out_f32) PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_direct: wide output must be 16-bit NHWC");
     a.wide_f16 = d->out_f16;
-    dim3 grid((unsigned)((npix + 255) / 256), d->cout / 32);
+    if (npix * 4 >= (1ll << 31)) PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_direct: %lld pixels (the few-cin kernel indexes with 32 bits)", npix);
+    long long gx = (npix * 4 + 255) / 256;   // four lanes (channel octets) per pixel; at most 4096 persistent workgroups
+    static const long long cap = getenv("PTI_FEWCIN_WGS") ? atoll(getenv("PTI_FEWCIN_WGS")) : 4096;
+    if (gx > cap) gx = cap;
+    dim3 grid((unsigned)gx, d->cout / 32);
     PTI_LAUNCH(direct_fewcin_kernel, grid, dim3(256), 0, (hipStream_t)s, a);
   } else if (d->cout <= 16 && d->cin % 8 == 0 && d->cin >= 8 && d->cin <= 512 && !(d->cin & (d->cin - 1))) {
     if (d->in_f32) PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_direct: wide input must be 16-bit NHWC");

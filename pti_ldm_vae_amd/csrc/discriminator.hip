@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void pd_lsgan_finalize_kernel(float* __restric
 
 int stream_blocks(long long items) {
   long long b = (items + 255) / 256;
-  return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
+  return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));   // persistent grid-stride workgroups (tiny workgroups by the ten-thousand are dispatch-bound)
 }
 
 bool pd_channels_ok(int c) { return c >= 32 && c <= 256 && !(c & (c - 1)); }

@@ -286,11 +286,12 @@ class _DirectConv:
         # The launch that PRODUCES the narrow side (conv_out forward: wide -> narrow; conv_in data gradient: wide ->
         # narrow) is a reduction over the wide channels per output.  The direct kernel does it with VALU dot products
         # reduced across lanes, which is fine for 1-4 narrow channels and collapses for 16 (AR config: 256 -> 16 at 64^2
-        # took 2.7 ms per launch, 25 % of the step).  For 5..32 narrow channels it goes to the MFMA conv instead, with
+        # took 2.7 ms per launch, 25 % of the step; config A: 128 -> 4 at 32^2 took 70 us for an 8 MB map).  For 4..32 narrow
+        # channels it goes to the MFMA conv instead, with
         # the narrow channels zero-padded to one 32-wide MFMA tile (`wpad` = fp32 master copy with the padding, `wp_mfma`
         # its packed operand; Engine.refresh_weights keeps both current) and the result sliced back.
         narrow, wide = min(self.cin, self.cout), max(self.cin, self.cout)
-        self.mfma_narrow = 4 < narrow <= 32 and wide % 32 == 0
+        self.mfma_narrow = 4 <= narrow <= 32 and wide % 32 == 0
         self.wpad = self.wp_mfma = None
         self.pack_f16 = False
 
