@@ -37,6 +37,12 @@ def build_model(dev):
     return VAEModel.from_config(CFG).to(dev)
 
 
+def build_disc(dev):
+    from pti_ldm_vae_amd.models import PatchDiscriminator
+    torch.manual_seed(SEED + 1)
+    return PatchDiscriminator().to(dev)
+
+
 def main(outdir):
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group(backend="gloo", init_method="env://")
@@ -68,6 +74,28 @@ def main(outdir):
     both = [torch.zeros_like(chk) for _ in range(world)]
     dist.all_gather(both, chk)
     res["ranks_agree"] = bool(torch.equal(both[0], both[1]))
+
+    # ---- native trainer with the adversarial branch: the discriminator has its own arena, exchange and Adam ----
+    try:
+        from pti_ldm_vae_amd.models import PatchDiscriminator
+        m3 = build_model(dev)
+        disc = build_disc(dev)
+        if rank == 1:
+            with torch.no_grad():
+                disc.param_arena.add_(0.25)      # the constructor must broadcast rank 0's discriminator too
+        tr3 = VAETrainer(m3, lr=LR, world_size=world, discriminator=disc, adv_weight=0.1, adv_no_activation_leastsq=True)
+        out3 = tr3.step(xs, es, adversarial=True)
+        torch.cuda.synchronize()
+        if rank == 0:
+            torch.save({"d_grad_sum": disc.grad_arena.detach().cpu(), "d_params": disc.param_arena.detach().cpu(),
+                        "g_grad_sum": m3.autoencoder.grad_arena.detach().cpu()}, os.path.join(outdir, "adv_rank0.pt"))
+        chk = torch.stack([disc.grad_arena.double().sum(), disc.param_arena.double().sum()]).cpu()
+        both = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(both, chk)
+        res["adv"] = {"ok": True, "ranks_agree": bool(torch.equal(both[0], both[1])), "adv_gen": out3["adv_gen"].item(),
+                      "adv_disc": out3["adv_disc"].item()}
+    except Exception as ex:
+        res["adv"] = {"ok": False, "error": repr(ex)}
 
     # ---- drop-in path under DistributedDataParallel(find_unused_parameters=True), as train_vae.py:282 wraps it ----
     try:

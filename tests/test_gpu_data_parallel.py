@@ -63,3 +63,30 @@ def test_dropin_model_under_torch_ddp_wrapper(dev, dp_job):
     for r in (r0, r1):
         assert r["ddp"]["ok"], r["ddp"]
         assert r["ddp"]["finite"] and r["ddp"]["ranks_agree"] and r["ddp"]["grad_abs_sum"] > 0
+
+
+def test_two_rank_adversarial_step_equals_single_rank_full_batch(dev, dp_job):
+    """The adversarial branch under data parallelism: the discriminator's gradient arena is exchanged (one bucket) and
+    averaged like the generator's, its parameters are broadcast at construction, and two half-batch ranks equal one
+    full-batch rank (InstanceNorm is per sample, the losses are batch means)."""
+    import dp_gpu_worker as W
+    from pti_ldm_vae_amd.trainer import VAETrainer
+    outdir = dp_job()
+    r0, r1 = (json.load(open(os.path.join(outdir, f"rank{r}.json"))) for r in (0, 1))
+    assert r0["adv"]["ok"] and r1["adv"]["ok"], (r0["adv"], r1["adv"])
+    assert r0["adv"]["ranks_agree"] and r1["adv"]["ranks_agree"]
+    dp = torch.load(os.path.join(outdir, "adv_rank0.pt"), weights_only=True)
+    model, disc = W.build_model(dev), W.build_disc(dev)
+    x, eps = W.fixed_inputs()
+    tr = VAETrainer(model, lr=W.LR * 2, discriminator=disc, adv_weight=0.1, adv_no_activation_leastsq=True)
+    out = tr.step(x.to(dev), eps.to(dev), adversarial=True)
+    torch.cuda.synchronize()
+    gd_full, gg_full = disc.grad_arena.detach().cpu(), model.autoencoder.grad_arena.detach().cpu()
+    rel_d = ((dp["d_grad_sum"] / 2 - gd_full).norm() / gd_full.norm()).item()
+    rel_g = ((dp["g_grad_sum"] / 2 - gg_full).norm() / gg_full.norm()).item()
+    dmax = (dp["d_params"] - disc.param_arena.detach().cpu()).abs().max().item()
+    print(f"[dp2 adv] D grad relL2 {rel_d:.2e}, G grad relL2 {rel_g:.2e}, D param max|diff| {dmax:.2e}; adv_disc "
+          f"{0.5 * (r0['adv']['adv_disc'] + r1['adv']['adv_disc']):.5f} vs {out['adv_disc'].item():.5f}")
+    assert rel_d <= 2e-3 and rel_g <= 2e-3
+    assert dmax <= 2.5 * 2 * W.LR
+    assert 0.5 * (r0["adv"]["adv_disc"] + r1["adv"]["adv_disc"]) == pytest.approx(out["adv_disc"].item(), rel=1e-3)
