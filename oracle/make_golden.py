@@ -13,6 +13,8 @@ Part 2 (parity unpinned — MONAI absent): runs this repo's own CPU fp32 oracle
 reconstruction / loss scalars / per-parameter gradient norms in
 ``tests/golden/model_golden_*.npz`` so later refactors of the oracle and the HIP path
 are checked against a frozen vector.
+
+Part 3 (parity unpinned, same reason): the oracle PatchDiscriminator -> ``tests/golden/disc_golden.npz``.
 """
 from __future__ import annotations
 
@@ -123,6 +125,33 @@ def model_golden():
               "params", sum(p.numel() for p in model.parameters()))
 
 
+def discriminator_golden():
+    """Part 3 (parity unpinned -- MONAI absent): the oracle PatchDiscriminator (oracle/patch_discriminator.py) on a seeded
+    state (weights at 5x the initialisation scale, as the GPU tests use) and a seeded 96x96 input: logits, the three
+    least-squares losses, gradient of the generator term w.r.t. the input, per-parameter gradient norms of the
+    discriminator loss -> tests/golden/disc_golden.npz (state and input are regenerated from the seeds by the tests)."""
+    from oracle.patch_discriminator import PatchDiscriminator, patch_adversarial_loss as pal
+    torch.manual_seed(2024)
+    ref = PatchDiscriminator()
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.mul_(5.0)
+    g = torch.Generator().manual_seed(2025)
+    x = torch.randn(2, 1, 96, 96, generator=g) * 0.8
+    real = torch.randn(2, 1, 96, 96, generator=g) * 0.8 + 0.2
+    xg = x.clone().requires_grad_(True)
+    logits = ref(xg)[-1]
+    gen = pal(logits, True, False)
+    dx, = torch.autograd.grad(gen, xg)
+    ref.zero_grad(set_to_none=True)
+    lf, lr = pal(ref(x)[-1], False, True), pal(ref(real)[-1], True, True)
+    (0.5 * (lf + lr)).backward()
+    np.savez_compressed(os.path.join(GOLD, "disc_golden.npz"), logits=logits.detach().numpy(), gen=float(gen), fake=float(lf),
+                        real=float(lr), dx=dx.numpy(),
+                        **{"gnorm_" + n.replace(".", "_"): float(p.grad.norm()) for n, p in ref.named_parameters()})
+    print("wrote disc_golden.npz")
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     if os.path.isdir(REF):
@@ -130,3 +159,4 @@ if __name__ == "__main__":
     else:
         print("reference absent: losses_golden.json not regenerated")
     model_golden()
+    discriminator_golden()

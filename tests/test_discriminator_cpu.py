@@ -84,3 +84,33 @@ def test_oracle_structure():
     assert float(patch_adversarial_loss(lo, True, True)) == pytest.approx(((-0.1 - 1) ** 2 + (0.5 - 1) ** 2) / 2)
     assert float(patch_adversarial_loss(lo, False, False)) == float(patch_adversarial_loss(lo, True, True))   # generator: always "real"
     assert float(patch_adversarial_loss(lo, False, True)) == pytest.approx((0.01 + 0.25) / 2)
+
+
+def _golden_state():
+    """The seeded state and inputs of oracle/make_golden.py::discriminator_golden."""
+    from oracle.patch_discriminator import PatchDiscriminator as Oracle
+    torch.manual_seed(2024)
+    ref = Oracle()
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.mul_(5.0)
+    g = torch.Generator().manual_seed(2025)
+    x = torch.randn(2, 1, 96, 96, generator=g) * 0.8
+    real = torch.randn(2, 1, 96, 96, generator=g) * 0.8 + 0.2
+    return ref, x, real
+
+
+def test_oracle_reproduces_frozen_discriminator_vectors():
+    """tests/golden/disc_golden.npz freezes the oracle's outputs (parity unpinned w.r.t. MONAI: a regression vector, so
+    that a later edit of the restatement cannot move silently)."""
+    import os
+    import numpy as np
+    from oracle.patch_discriminator import patch_adversarial_loss as pal
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "disc_golden.npz"))
+    ref, x, real = _golden_state()
+    with torch.no_grad():
+        logits = ref(x)[-1]
+        assert np.allclose(logits.numpy(), gold["logits"], rtol=1e-5, atol=1e-5)
+        assert float(pal(logits, True, False)) == pytest.approx(float(gold["gen"]), rel=1e-5)
+        assert float(pal(logits, False, True)) == pytest.approx(float(gold["fake"]), rel=1e-5)
+        assert float(pal(ref(real)[-1], True, True)) == pytest.approx(float(gold["real"]), rel=1e-5)

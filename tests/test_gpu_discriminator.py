@@ -498,3 +498,34 @@ def test_native_step_with_perceptual_term_vs_oracle(dev):
     assert float(res["perceptual"]) > 0
     with pytest.raises(ValueError):
         VAETrainer(model, lr=1e-4, perceptual_weight=1.0)
+
+
+def test_engine_vs_frozen_golden_vectors(dev):
+    """HIP discriminator against tests/golden/disc_golden.npz (oracle outputs frozen by oracle/make_golden.py on a seeded
+    state and input): logits, the three least-squares losses, parameter-gradient norms of the discriminator loss."""
+    import os
+    import numpy as np
+    from test_discriminator_cpu import _golden_state
+    from pti_ldm_vae_amd.models import PatchDiscriminator
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "disc_golden.npz"))
+    ref, x, real = _golden_state()
+    net = PatchDiscriminator()
+    net.load_state_dict(ref.state_dict())
+    net = net.to(dev)
+    eng = net.engine()
+    ctx, rctx = eng.forward(x.to(dev), save=True), eng.forward(real.to(dev), save=True)
+    logits = eng.logits(ctx).cpu().numpy()
+    span = float(gold["logits"].max() - gold["logits"].min())
+    assert float(np.abs(logits - gold["logits"]).max()) <= 2e-2 * span
+    gen, _ = eng.lsgan(ctx, target_is_real=True, want_grad=False)
+    fake, d_f = eng.lsgan(ctx, target_is_real=False, weight=0.5)
+    realv, d_r = eng.lsgan(rctx, target_is_real=True, weight=0.5)
+    assert float(gen) == pytest.approx(float(gold["gen"]), rel=1e-2)
+    assert float(fake) == pytest.approx(float(gold["fake"]), rel=1e-2)
+    assert float(realv) == pytest.approx(float(gold["real"]), rel=1e-2)
+    eng.backward(ctx, d_f, want_wgrad=True)
+    eng.backward(rctx, d_r, want_wgrad=True)
+    torch.cuda.synchronize()
+    for n, _ in net.named_parameters():
+        want = float(gold["gnorm_" + n.replace(".", "_")])
+        assert float(net.grad_view(n).norm()) == pytest.approx(want, rel=6e-2), n   # kink-limited, see _pin_forward_state
