@@ -1104,7 +1104,9 @@ extern "C" int pti_conv_wgrad_mfma_partials(const void* x, const void* dy, const
   // load latency x bytes in flight: 64->64@128^2 70.3 -> 64.2 us, 128->128@64^2 70.5 -> 62.7 us, nearest-2x 64->64 231
   // -> 202 us; the single-block 32->32@256^2 shape 89.0 -> 82.5 us with 1024 workgroups (768: 83.3, 1152: 83.9).
   const bool plain = d->prologue == PTI_PRO_NONE && cob == 1;
-  int S = (v3 ? (cob == 2 ? 512 : (plain ? (tiles_cc == 1 ? 1024 : 1280) : 768)) : 512) / tiles_cc;
+  // 1x1 / stride-2 launches (v1 kernel): 512 workgroups by default; PTI_WGRAD_V1_WGS overrides (tuning)
+  static const int v1_wgs = getenv("PTI_WGRAD_V1_WGS") ? atoi(getenv("PTI_WGRAD_V1_WGS")) : 512;
+  int S = (v3 ? (cob == 2 ? 512 : (plain ? (tiles_cc == 1 ? 1024 : 1280) : 768)) : v1_wgs) / tiles_cc;
   if (S > a.ntiles / 4) S = a.ntiles / 4;
   const int scap = v3 ? (plain ? 1024 : 512) : 256;
   if (S > scap) S = scap;
