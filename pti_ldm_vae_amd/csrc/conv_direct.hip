@@ -315,6 +315,7 @@ struct WGArgs {
   long long dw_stride_tap, dw_stride_cw, dw_stride_k;
 };
 
+template <int TH_>   // tile height: 16 on large maps (half the barriers / halo staging per pixel: 108 -> 92 us at 256^2 x 32), 8 otherwise
 __global__ __launch_bounds__(256) void wgrad_direct_kernel(WGArgs a) {
   const int NC = a.CW / 8;
   const int lc = threadIdx.x % NC, lp = threadIdx.x / NC;
@@ -335,12 +336,12 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(WGArgs a) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
   // "wide" is the centre of the stencil:  dW[tap][cw] = sum_p wide[p] * narrow[p - sgn*off_tap].
-  // A block walks 8x16-pixel tiles (tile = blockIdx.x, + gridDim.x, ...), accumulating in registers across tiles.
+  // A block walks TH_ x 16-pixel tiles (tile = blockIdx.x, + gridDim.x, ...), accumulating in registers across tiles.
   // Per tile the narrow halo (10x18 scalars of channel k, zero outside the image) is staged in LDS once, so the inner
   // loop is: one 16-byte wide load (+ prologue, applied ONCE), 9 LDS reads, 72 FMAs -- no bounds checks, no 64-bit
   // strided addressing.  (The first version fetched the 9 narrow neighbours from global memory per pixel piece with
   // per-lane 64-bit index arithmetic: 0.5 TB/s.)
-  constexpr int TH_ = 8, TW_ = 16, HW_ = TW_ + 2, NPH = (TH_ + 2) * HW_;
+  constexpr int TW_ = 16, HW_ = TW_ + 2, NPH = (TH_ + 2) * HW_;
   __shared__ float nar[2][NPH];
   const int tiles_x = (a.W + TW_ - 1) / TW_, tiles_y = (a.H + TH_ - 1) / TH_;
   const int ntiles = a.N * tiles_x * tiles_y;
@@ -368,15 +369,15 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(WGArgs a) {
     int n, oy0, ox0;
     tile_org(tile, n, oy0, ox0);
     // stage the narrow halo of channel k (threads 0..NPH-1), accumulate its interior sum for the narrow-side bias
-    if (threadIdx.x < NPH) {
-      const int hy = threadIdx.x / HW_, hx = threadIdx.x - hy * HW_;
+    for (int hi = threadIdx.x; hi < NPH; hi += 256) {   // (18 x 18 = 324 halo values: two rounds)
+      const int hy = hi / HW_, hx = hi - hy * HW_;
       const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
       float v = 0.f;
       if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
         v = ld_narrow(a.narrow, n * a.ns[0] + iy * a.ns[1] + ix * a.ns[2] + k * a.ns[3], a.narrow_f32);
         if (hy >= 1 && hy <= TH_ && hx >= 1 && hx <= TW_) nsum += v;
       }
-      nar[buf][threadIdx.x] = v;
+      nar[buf][hi] = v;
     }
     if (a.prologue && n != cur_n) {
       cur_n = n;
@@ -587,7 +588,8 @@ extern "C" int pti_wgrad_direct(const void* wide, const void* narrow, float* dw,
   const int ppb = 256 / (cw / 8);
   // persistent blocks over 8x16-pixel tiles: 3 blocks/CU (160 VGPRs) x 256 CUs resident, >= 4 tiles each -- every
   // block writes 80*NC+1 partials, which for small maps would otherwise exceed the tensor itself
-  const long long ntiles = (long long)n * ((h + 7) / 8) * ((w + 15) / 16);
+  const int th = (long long)n * ((h + 15) / 16) * ((w + 15) / 16) >= 4 * 768 ? 16 : 8;   // enough 16-row tiles for every block?
+  const long long ntiles = (long long)n * ((h + th - 1) / th) * ((w + 15) / 16);
   long long blocks = ntiles / 4;
   if (blocks > 768) blocks = 768;
   if (blocks < 1) blocks = 1;
@@ -595,8 +597,10 @@ extern "C" int pti_wgrad_direct(const void* wide, const void* narrow, float* dw,
   while (blocks > 1 && blocks * cn * per * 4 > workspace_bytes) blocks /= 2;
   if (blocks * cn * per * 4 > workspace_bytes) PTI_FAIL(PTI_EINVAL, "wgrad_direct: workspace too small");
   a.part = (float*)workspace;
-  PTI_LAUNCH(wgrad_direct_kernel, dim3((unsigned)blocks, cn), dim3(256), 4 * 80 * (cw / 8) * sizeof(float),
-                     (hipStream_t)s, a);
+  if (th == 16)
+    PTI_LAUNCH(wgrad_direct_kernel<16>, dim3((unsigned)blocks, cn), dim3(256), 4 * 80 * (cw / 8) * sizeof(float), (hipStream_t)s, a);
+  else
+    PTI_LAUNCH(wgrad_direct_kernel<8>, dim3((unsigned)blocks, cn), dim3(256), 4 * 80 * (cw / 8) * sizeof(float), (hipStream_t)s, a);
   PTI_CHECK_LAUNCH("wgrad_direct");
   PTI_LAUNCH(wgrad_direct_finalize_kernel, dim3((unsigned)((per + 255) / 256), cn), dim3(256), 0, (hipStream_t)s, a,
                      (int)blocks);
