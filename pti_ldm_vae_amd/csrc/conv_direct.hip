@@ -315,7 +315,7 @@ struct WGArgs {
   long long dw_stride_tap, dw_stride_cw, dw_stride_k;
 };
 
-template <int TH_>   // tile height: 16 on large maps (half the barriers / halo staging per pixel: 108 -> 92 us at 256^2 x 32), 8 otherwise
+template <int TH_>   // tile height: 32 / 16 on large maps (fewer barriers and halo stagings per pixel), 8 otherwise
 __global__ __launch_bounds__(256) void wgrad_direct_kernel(WGArgs a) {
   const int NC = a.CW / 8;
   const int lc = threadIdx.x % NC, lp = threadIdx.x / NC;
@@ -588,7 +588,10 @@ extern "C" int pti_wgrad_direct(const void* wide, const void* narrow, float* dw,
   const int ppb = 256 / (cw / 8);
   // persistent blocks over 8x16-pixel tiles: 3 blocks/CU (160 VGPRs) x 256 CUs resident, >= 4 tiles each -- every
   // block writes 80*NC+1 partials, which for small maps would otherwise exceed the tensor itself
-  const int th = (long long)n * ((h + 15) / 16) * ((w + 15) / 16) >= 4 * 768 ? 16 : 8;   // enough 16-row tiles for every block?
+  // the tallest tile that still gives every block >= 4 tiles (256^2 x 32 channels, batch 32: 8 rows 108 us, 16 rows 91, 32 rows 82)
+  int th = 8;
+  for (int t = 32; t >= 16; t >>= 1)
+    if ((long long)n * ((h + t - 1) / t) * ((w + 15) / 16) >= 4 * 768) { th = t; break; }
   const long long ntiles = (long long)n * ((h + th - 1) / th) * ((w + 15) / 16);
   long long blocks = ntiles / 4;
   if (blocks > 768) blocks = 768;
@@ -597,7 +600,9 @@ extern "C" int pti_wgrad_direct(const void* wide, const void* narrow, float* dw,
   while (blocks > 1 && blocks * cn * per * 4 > workspace_bytes) blocks /= 2;
   if (blocks * cn * per * 4 > workspace_bytes) PTI_FAIL(PTI_EINVAL, "wgrad_direct: workspace too small");
   a.part = (float*)workspace;
-  if (th == 16)
+  if (th == 32)
+    PTI_LAUNCH(wgrad_direct_kernel<32>, dim3((unsigned)blocks, cn), dim3(256), 4 * 80 * (cw / 8) * sizeof(float), (hipStream_t)s, a);
+  else if (th == 16)
     PTI_LAUNCH(wgrad_direct_kernel<16>, dim3((unsigned)blocks, cn), dim3(256), 4 * 80 * (cw / 8) * sizeof(float), (hipStream_t)s, a);
   else
     PTI_LAUNCH(wgrad_direct_kernel<8>, dim3((unsigned)blocks, cn), dim3(256), 4 * 80 * (cw / 8) * sizeof(float), (hipStream_t)s, a);
