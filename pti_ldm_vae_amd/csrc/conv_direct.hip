@@ -468,28 +468,33 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(WGArgs a) {
   }
 }
 
-// out(+=) sum over blocks of the partials written by wgrad_direct_kernel
-__global__ __launch_bounds__(256) void wgrad_direct_finalize_kernel(WGArgs a, int nblocks) {
+// out(+=) sum over blocks of the partials written by wgrad_direct_kernel: 64 consecutive elements per workgroup, the 16
+// waves stride the block rows (8 loads in flight each) and fold through LDS in a fixed order (one thread per element
+// walking all ~768 rows took 26 us of serial round trips)
+__global__ __launch_bounds__(1024) void wgrad_direct_finalize_kernel(WGArgs a, int nblocks) {
+  __shared__ float red[16][64];
   const int NC = a.CW / 8, k = blockIdx.y;
-  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + lane;
   const int per = 80 * NC + 1;
-  if (e >= per) return;
-  const float* base = a.part + (size_t)k * nblocks * per + e;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
-  int b = 0;
-  for (; b + 7 < nblocks; b += 8) {
-    s0 += base[(size_t)b * per];
-    s1 += base[(size_t)(b + 1) * per];
-    s2 += base[(size_t)(b + 2) * per];
-    s3 += base[(size_t)(b + 3) * per];
-    s4 += base[(size_t)(b + 4) * per];
-    s5 += base[(size_t)(b + 5) * per];
-    s6 += base[(size_t)(b + 6) * per];
-    s7 += base[(size_t)(b + 7) * per];
+  float acc = 0.f;
+  if (e < per) {
+    const float* base = a.part + (size_t)k * nblocks * per + e;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int b = w;
+    for (; b + 7 * 16 < nblocks; b += 8 * 16) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s[u] += base[(size_t)(b + 16 * u) * per];
+    }
+    for (; b < nblocks; b += 16) s[0] += base[(size_t)b * per];
+    acc = ((s[0] + s[4]) + (s[1] + s[5])) + ((s[2] + s[6]) + (s[3] + s[7]));
   }
-  for (; b < nblocks; ++b) s0 += base[(size_t)b * per];
-  s0 += s4; s1 += s5; s2 += s6; s3 += s7;
-  const float v = (s0 + s1) + (s2 + s3);
+  red[w][lane] = acc;
+  __syncthreads();
+  if (w != 0 || e >= per) return;
+  float v = red[0][lane];
+#pragma unroll
+  for (int g = 1; g < 16; ++g) v += red[g][lane];
   const int ntap = a.KS * a.KS;
   if (e == 80 * NC) {
     if (a.dbias_narrow) a.dbias_narrow[k] += v;
@@ -607,7 +612,7 @@ extern "C" int pti_wgrad_direct(const void* wide, const void* narrow, float* dw,
   else
     PTI_LAUNCH(wgrad_direct_kernel<8>, dim3((unsigned)blocks, cn), dim3(256), 4 * 80 * (cw / 8) * sizeof(float), (hipStream_t)s, a);
   PTI_CHECK_LAUNCH("wgrad_direct");
-  PTI_LAUNCH(wgrad_direct_finalize_kernel, dim3((unsigned)((per + 255) / 256), cn), dim3(256), 0, (hipStream_t)s, a,
+  PTI_LAUNCH(wgrad_direct_finalize_kernel, dim3((unsigned)((per + 63) / 64), cn), dim3(1024), 0, (hipStream_t)s, a,
                      (int)blocks);
   PTI_CHECK_LAUNCH("wgrad_direct");
   return PTI_OK;
