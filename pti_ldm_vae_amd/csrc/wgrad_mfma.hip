@@ -548,6 +548,12 @@ constexpr int W4_STG = 20 * 1024, W4_DP = 3, W4_NSTAGE = 2 * (W4_DP + 1), W4_IMG
 // reads per MFMA need more accumulators per wave (an x fragment is shared by the kernel rows of up to three output rows
 // and by every output-channel block a wave owns): one wave per SIMD with two blocks in 288 registers (0.44 fragments
 // per MFMA instead of 0.78) is the design this points to.
+// (Tried on that theory and REJECTED: reading only the kw = 0 x fragment of a halo row and shifting the kw = 1, 2
+// fragments out of it in registers -- 4 v_alignbit + 1 v_permlane32_swap + two 2-byte LDS reads for the entering pixels
+// per row instead of 4 transposing reads: 28 -> 12 fragment reads per wave and tile.  Bit-exact, and 1.7 % SLOWER per
+// step on both models: the longer dependent chain in front of each row's MFMAs costs more than the LDS time it saves,
+// so LDS read bandwidth is not the binding limit either; what remains is the per-tile critical path -- wait, barrier,
+// transposing reads, 18 dependent-issue MFMAs -- with two waves per SIMD to hide it.)
 constexpr int W4_STG2 = 28 * 1024, W4_DP2 = 4, W4_NST2 = W4_DP2 + 1;
 constexpr int W4_LDS = (W4_NSTAGE * W4_STG > 4 * W4_IMG + 1024) ? W4_NSTAGE * W4_STG : 4 * W4_IMG + 1024;
 
