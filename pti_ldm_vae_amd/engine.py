@@ -360,6 +360,9 @@ class Engine:
         self.wgrad_batch_max = max(1, min(ops.L.WGRAD_BATCH_MAX, int(os.environ.get("PTI_WGRAD_BATCH", "16"))))
         self.batch_wgrad = self.wgrad_batch_max > 1
         self._wgrad_jobs, self._ready_queue = [], []
+        # inference encodes replay a HIP graph per input shape (see _encode_graphed)
+        self.encode_graphs = os.environ.get("PTI_ENCODE_GRAPH", "1") == "1"
+        self._enc_graphs, self._enc_graph_version = {}, None
         ops.L.lib()  # fail loudly now if the HIP extension is missing
         for c in net.channels:
             if c % 32:
@@ -724,8 +727,46 @@ class Engine:
         params = self._region_params(0)
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for _, p in params)):
             return _EncodeFn.apply(self, x, *[p for _, p in params])
+        if self.encode_graphs:
+            out = self._encode_graphed(x)
+            if out is not None:
+                return out
         mu, sigma, _ = self.encode_forward(x, save=False)
         return mu, sigma
+
+    def _encode_graphed(self, x):
+        """Inference encode (no autograd) replayed from a HIP graph: the encoder forward is ~70 launches, and at the
+        batch sizes the regression / inference scripts use (reg_edente_from_dente.json: 8) the host needs longer to
+        enqueue them (~1.1 ms) than the GPU to run them.  One graph per input shape (at most four; further shapes run
+        eagerly), captured after an eager warm-up; dropped and re-captured when the weights were re-packed (the direct
+        convs' operands move).  Outputs are copies of the graph's static buffers.  PTI_ENCODE_GRAPH=0 turns it off."""
+        if ops.KERNEL_PROFILE is not None:      # per-kernel timing wants the eager launches
+            return None
+        x = self._check_input(x, self.net.in_channels, "encode")
+        self.refresh_weights()
+        if self._enc_graph_version != self.packed_version:
+            self._enc_graphs.clear()
+            self._enc_graph_version = self.packed_version
+        key = tuple(x.shape)
+        ent = self._enc_graphs.get(key)
+        if ent is None:
+            if len(self._enc_graphs) >= 4:
+                return None
+            sx = x.clone()
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream(device=self.dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):           # warm-up outside the capture (allocator, lazy state)
+                self.encode_forward(sx, save=False)
+            cur.wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                mu, sigma, _ = self.encode_forward(sx, save=False)
+            ent = self._enc_graphs[key] = (g, sx, mu, sigma)
+        g, sx, mu, sigma = ent
+        sx.copy_(x)
+        g.replay()
+        return mu.clone(), sigma.clone()
 
     def decode(self, z):
         params = self._region_params(1)

@@ -92,3 +92,36 @@ def test_regression_script_end_to_end_on_tiff_directory(dev, tmp_path):
     assert "val/mae_height_0" in lines[-1] and "val/best_loss_mse" in lines[-1]
     ck = torch.load(wd / "head_last.pth", weights_only=True)
     assert ck["epoch"] == 6 and ck["targets"] == ["height_0", "width_0"] and ck["latent_dim"] == 4 * 32 * 32
+
+
+def test_inference_encode_graph_replay_equals_eager(dev):
+    """``encode_deterministic`` under no_grad replays a HIP graph per input shape (engine._encode_graphed): same bits as
+    the eager launches, across repeated calls, a second shape, and a weight update (the graphs are dropped and
+    re-captured when the packed operands change)."""
+    from pti_ldm_vae_amd.models import VAEModel
+    cfg = dict(spatial_dims=2, in_channels=1, out_channels=1, latent_channels=4, channels=[32, 64], num_res_blocks=1,
+               norm_num_groups=16, norm_eps=1e-6, attention_levels=[False, True], with_encoder_nonlocal_attn=True,
+               with_decoder_nonlocal_attn=True)
+    torch.manual_seed(0)
+    m = VAEModel.from_config(cfg).to(dev).eval()
+    eng = m.autoencoder.engine()
+    xs = [torch.randn(3, 1, 64, 64, device=dev), torch.randn(3, 1, 64, 64, device=dev), torch.randn(2, 1, 32, 96, device=dev)]
+    with torch.no_grad():
+        eng.encode_graphs = False
+        eager = [m.encode_deterministic(x).clone() for x in xs]
+        eng.encode_graphs = True
+        for _ in range(2):
+            for x, e in zip(xs, eager):
+                assert torch.equal(m.encode_deterministic(x), e)
+        assert len(eng._enc_graphs) == 2
+        # weights change -> re-pack -> the captured graphs are stale and must not be replayed
+        for p in m.parameters():
+            p.mul_(1.01)
+        eng.encode_graphs = False
+        eager2 = m.encode_deterministic(xs[0]).clone()
+        eng.encode_graphs = True
+        got = m.encode_deterministic(xs[0])
+        assert torch.equal(got, eager2) and not torch.equal(got, eager[0])
+    # with autograd on a parameter-requiring-grad model the autograd path is taken (no graph)
+    out = m.autoencoder.encode(xs[0])[0]
+    assert out.requires_grad
