@@ -135,6 +135,11 @@ class VAETrainer:
         # the GPU always has the next step queued, the host never gets further ahead than that.
         self.max_steps_in_flight = int(os.environ.get("PTI_MAX_STEPS_IN_FLIGHT", "2"))
         self._step_done = collections.deque()
+        # opt-in HIP-graph mode for the plain step (one GPU, no AR / perceptual / adversarial term): forward + loss +
+        # backward of a fixed batch shape are captured once and replayed, Adam stays eager (its bias corrections change
+        # every step).  Host time per step 5.2 -> ~3 ms: matters where the step is host-bound (batch <= 8 on config A).
+        self.step_graph = os.environ.get("PTI_STEP_GRAPH", "0") == "1"
+        self._graphs, self._eager_steps = {}, 0
         # adversarial branch: PatchDiscriminator with its own flat Adam (train_vae.py:304: same lr x world) and its own
         # gradient exchange (one bucket: the discriminator is 2.8 MB of fp32 gradients)
         self.disc, self.adv_weight = discriminator, float(adv_weight)
@@ -244,6 +249,53 @@ class VAETrainer:
         d_recon.add_(g, alpha=self.perceptual_weight)
         return p.detach()
 
+    def _plain_fwd_bwd(self, images, eps):
+        """zero_grad -> forward -> L1|L2 + kl_weight*KL -> backward, without any optional term and without host-side
+        decisions: the part of the step a HIP graph can hold.  Returns the [recon, kl] device pair."""
+        net, eng = self.net, self.eng
+        net.grad_arena.zero_()
+        mu, sigma, c_enc = eng.encode_forward(images, save=True)
+        z = torch.addcmul(mu, eps, sigma)
+        recon, c_dec = eng.decode_forward(z, save=True)
+        third = sigma if net.third_output == "sigma" else 2.0 * torch.log(sigma)
+        out2 = torch.zeros(2, dtype=torch.float32, device=recon.device)
+        d_recon, d_mu, d_third = torch.empty_like(recon), torch.empty_like(mu), torch.empty_like(third)
+        ops.vae_loss(recon, images, mu, third, out2, d_recon, d_mu, d_third, l2=self.l2, third_mode=self.third_mode,
+                     kl_weight=self.kl_weight)
+        dz = eng.decode_backward(c_dec, d_recon, want_dz=True, join=False)
+        d_sigma = d_third if net.third_output == "sigma" else d_third * (2.0 / sigma)
+        d_mu = d_mu + dz
+        d_sigma = torch.addcmul(d_sigma, dz, eps)
+        eng.encode_backward(c_enc, d_mu, d_sigma, want_dx=False)
+        return out2
+
+    def _step_graphed(self, images, eps):
+        """One plain step through a captured graph (see ``step_graph``); None when this call must run eagerly (the first
+        two steps, which settle the lazily built state, and more than four batch shapes)."""
+        key = tuple(images.shape)
+        st = self._graphs.get(key)
+        if st is None:
+            if self._eager_steps < 2 or len(self._graphs) >= 4 or ops.KERNEL_PROFILE is not None:
+                return None
+            net = self.net
+            down = 2 ** (len(net.channels) - 1)
+            gx = images.detach().float().contiguous().clone()
+            geps = torch.zeros(images.shape[0], net.latent_channels, images.shape[2] // down, images.shape[3] // down,
+                               dtype=torch.float32, device=images.device)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out2 = self._plain_fwd_bwd(gx, geps)
+            st = self._graphs[key] = (g, gx, geps, out2)
+        g, gx, geps, out2 = st
+        gx.copy_(images)
+        if eps is None:
+            geps.normal_(generator=self.gen)        # the same draws torch.randn(..., generator=self.gen) makes eagerly
+        else:
+            geps.copy_(eps)
+        g.replay()
+        return out2.clone()
+
     def step(self, images: torch.Tensor, eps: torch.Tensor | None = None, attributes: dict | None = None,
              adversarial: bool = False):
         """One optimiser step on ``images`` [B,C,H,W] fp32 (already on the device).  Returns a dict of
@@ -258,6 +310,17 @@ class VAETrainer:
         net, eng, red = self.net, self.eng, self.reducer
         while len(self._step_done) >= max(1, self.max_steps_in_flight):
             self._step_done.popleft().synchronize()
+        plain = (self.world == 1 and self.ar is None and not adversarial
+                 and not (self.perceptual is not None and self.perceptual_weight != 0.0))
+        if self.step_graph and plain and ops.KERNEL_PROFILE is None:
+            out2 = self._step_graphed(images, eps)
+            if out2 is not None:
+                self.opt.step(grad_scale=1.0)
+                done = torch.cuda.Event()
+                done.record()
+                self._step_done.append(done)
+                return {"loss": out2[0] + self.kl_weight * out2[1], "recon": out2[0], "kl": out2[1]}
+        self._eager_steps += 1
         net.grad_arena.zero_()
         red.begin_step()
         eng.grad_ready_cb = red.ready if self.world > 1 else None

@@ -181,3 +181,27 @@ def test_p_data_writes_need_mark_weights_dirty(dev):
         m.mark_weights_dirty()
         r1 = m.reconstruct_deterministic(x)
     assert (r1 - r0).abs().max().item() > 1e-4
+
+
+def test_step_graph_mode_is_bitwise_the_eager_step(dev):
+    """``PTI_STEP_GRAPH`` / ``trainer.step_graph``: forward + loss + backward replayed from a HIP graph (Adam eager) must give
+    the same bits as the eager step, with injected eps and with the trainer's own generator, and fall back to eager for
+    the first two steps and for steps with optional terms."""
+    from pti_ldm_vae_amd.trainer import VAETrainer
+    torch.manual_seed(5)
+    x = torch.randn(6, 2, 1, 64, 64, device=dev)
+    eps = torch.randn(6, 2, 4, 32, 32, device=dev)
+    ref = _model(dev)
+    state = {k: v.clone() for k, v in ref.state_dict().items()}
+    runs = []
+    for graph in (False, True):
+        m = _model(dev, seed=9)
+        m.load_state_dict(state)
+        tr = VAETrainer(m, lr=1e-3)
+        tr.step_graph = graph
+        losses = [tr.step(x[i], eps[i] if i % 2 == 0 else None)["loss"].item() for i in range(6)]
+        torch.cuda.synchronize()
+        runs.append((m.autoencoder.param_arena.clone(), losses, len(tr._graphs)))
+    assert runs[1][2] == 1 and runs[0][2] == 0
+    assert runs[0][1] == runs[1][1]
+    assert torch.equal(runs[0][0], runs[1][0])
