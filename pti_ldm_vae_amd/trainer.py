@@ -135,10 +135,13 @@ class VAETrainer:
         # the GPU always has the next step queued, the host never gets further ahead than that.
         self.max_steps_in_flight = int(os.environ.get("PTI_MAX_STEPS_IN_FLIGHT", "2"))
         self._step_done = collections.deque()
-        # opt-in HIP-graph mode for the plain step (one GPU, no AR / perceptual / adversarial term): forward + loss +
+        # HIP-graph mode for the plain step (one GPU, no AR / perceptual / adversarial term): forward + loss +
         # backward of a fixed batch shape are captured once and replayed, Adam stays eager (its bias corrections change
         # every step).  Host time per step 5.2 -> ~3 ms: matters where the step is host-bound (batch <= 8 on config A).
-        self.step_graph = os.environ.get("PTI_STEP_GRAPH", "0") == "1"
+        # PTI_STEP_GRAPH: 1 = always, 0 = never, unset = "auto": only where the step is host-bound -- at most 6 x 256^2
+        # pixels per batch (measured on config A: batch 4 5.52 -> 4.50 ms, batch 6 5.46 -> 5.13, batch 8 5.30 -> 5.71,
+        # batch 32 12.58 -> 13.05: the graph executes the two-stream DAG with less overlap than the eager streams)
+        self.step_graph = {"1": True, "0": False}.get(os.environ.get("PTI_STEP_GRAPH", ""), "auto")
         self._graphs, self._eager_steps = {}, 0
         # adversarial branch: PatchDiscriminator with its own flat Adam (train_vae.py:304: same lr x world) and its own
         # gradient exchange (one bucket: the discriminator is 2.8 MB of fp32 gradients)
@@ -272,7 +275,9 @@ class VAETrainer:
     def _step_graphed(self, images, eps):
         """One plain step through a captured graph (see ``step_graph``); None when this call must run eagerly (the first
         two steps, which settle the lazily built state, and more than four batch shapes)."""
-        key = tuple(images.shape)
+        # everything the captured launches bake in besides the weights: shape, loss settings, stream layout
+        key = (tuple(images.shape), self.l2, self.kl_weight, self.third_mode, self.eng.wgrad_stream is None,
+               self.eng.wgrad_batch_max)
         st = self._graphs.get(key)
         if st is None:
             if self._eager_steps < 2 or len(self._graphs) >= 4 or ops.KERNEL_PROFILE is not None:
@@ -312,7 +317,8 @@ class VAETrainer:
             self._step_done.popleft().synchronize()
         plain = (self.world == 1 and self.ar is None and not adversarial
                  and not (self.perceptual is not None and self.perceptual_weight != 0.0))
-        if self.step_graph and plain and ops.KERNEL_PROFILE is None:
+        use_graph = self.step_graph is True or (self.step_graph == "auto" and images.shape[0] * images.shape[2] * images.shape[3] <= 6 * 65536)
+        if use_graph and plain and ops.KERNEL_PROFILE is None:
             out2 = self._step_graphed(images, eps)
             if out2 is not None:
                 self.opt.step(grad_scale=1.0)

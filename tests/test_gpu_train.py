@@ -203,5 +203,6 @@ def test_step_graph_mode_is_bitwise_the_eager_step(dev):
         torch.cuda.synchronize()
         runs.append((m.autoencoder.param_arena.clone(), losses, len(tr._graphs)))
     assert runs[1][2] == 1 and runs[0][2] == 0
+    assert VAETrainer(_model(dev), lr=1e-3).step_graph == "auto"      # default: graphs only where the step is host-bound
     assert runs[0][1] == runs[1][1]
     assert torch.equal(runs[0][0], runs[1][0])
