@@ -362,7 +362,7 @@ class Engine:
         self._wgrad_jobs, self._ready_queue = [], []
         # inference encodes replay a HIP graph per input shape (see _encode_graphed)
         self.encode_graphs = os.environ.get("PTI_ENCODE_GRAPH", "1") == "1"
-        self._enc_graphs, self._enc_graph_version = {}, None
+        self._enc_graphs, self._dec_graphs, self._enc_graph_version = {}, {}, None
         ops.L.lib()  # fail loudly now if the HIP extension is missing
         for c in net.channels:
             if c % 32:
@@ -746,6 +746,7 @@ class Engine:
         self.refresh_weights()
         if self._enc_graph_version != self.packed_version:
             self._enc_graphs.clear()
+            self._dec_graphs.clear()
             self._enc_graph_version = self.packed_version
         key = tuple(x.shape)
         ent = self._enc_graphs.get(key)
@@ -772,8 +773,43 @@ class Engine:
         params = self._region_params(1)
         if torch.is_grad_enabled() and (z.requires_grad or any(p.requires_grad for _, p in params)):
             return _DecodeFn.apply(self, z, *[p for _, p in params])
+        if self.encode_graphs:
+            out = self._decode_graphed(z)
+            if out is not None:
+                return out
         recon, _ = self.decode_forward(z, save=False)
         return recon
+
+    def _decode_graphed(self, z):
+        """Inference decode replayed from a HIP graph per latent shape -- the mirror of ``_encode_graphed``."""
+        if ops.KERNEL_PROFILE is not None:
+            return None
+        z = self._check_input(z, self.Lc, "decode")
+        self.refresh_weights()
+        if self._enc_graph_version != self.packed_version:
+            self._enc_graphs.clear()
+            self._dec_graphs.clear()
+            self._enc_graph_version = self.packed_version
+        key = tuple(z.shape)
+        ent = self._dec_graphs.get(key)
+        if ent is None:
+            if len(self._dec_graphs) >= 4:
+                return None
+            sz = z.clone()
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream(device=self.dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                self.decode_forward(sz, save=False)
+            cur.wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                recon, _ = self.decode_forward(sz, save=False)
+            ent = self._dec_graphs[key] = (g, sz, recon)
+        g, sz, recon = ent
+        sz.copy_(z)
+        g.replay()
+        return recon.clone()
 
     def _prepare_grads(self, which):
         """Zero this region of the gradient arena unless the parameters' .grad already alias it (then

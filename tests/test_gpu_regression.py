@@ -122,6 +122,13 @@ def test_inference_encode_graph_replay_equals_eager(dev):
         eng.encode_graphs = True
         got = m.encode_deterministic(xs[0])
         assert torch.equal(got, eager2) and not torch.equal(got, eager[0])
+        # the decoder side: reconstruct_deterministic = graph-replayed encode + graph-replayed decode
+        eng.encode_graphs = False
+        rec_e = m.reconstruct_deterministic(xs[2]).clone()
+        eng.encode_graphs = True
+        for _ in range(2):
+            assert torch.equal(m.reconstruct_deterministic(xs[2]), rec_e)
+        assert len(eng._dec_graphs) == 1
     # with autograd on a parameter-requiring-grad model the autograd path is taken (no graph)
     out = m.autoencoder.encode(xs[0])[0]
     assert out.requires_grad
