@@ -761,7 +761,7 @@ class Engine:
                 self.encode_forward(sx, save=False)
             cur.wait_stream(side)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):   # loader threads may issue copies meanwhile
                 mu, sigma, _ = self.encode_forward(sx, save=False)
             ent = self._enc_graphs[key] = (g, sx, mu, sigma)
         g, sx, mu, sigma = ent
@@ -803,7 +803,7 @@ class Engine:
                 self.decode_forward(sz, save=False)
             cur.wait_stream(side)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):   # loader threads may issue copies meanwhile
                 recon, _ = self.decode_forward(sz, save=False)
             ent = self._dec_graphs[key] = (g, sz, recon)
         g, sz, recon = ent

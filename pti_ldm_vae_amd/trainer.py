@@ -289,7 +289,7 @@ class VAETrainer:
                                dtype=torch.float32, device=images.device)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):   # loader threads may issue copies meanwhile
                 out2 = self._plain_fwd_bwd(gx, geps)
             st = self._graphs[key] = (g, gx, geps, out2)
         g, gx, geps, out2 = st
