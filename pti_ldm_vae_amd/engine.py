@@ -761,8 +761,15 @@ class Engine:
                 self.encode_forward(sx, save=False)
             cur.wait_stream(side)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):   # loader threads may issue copies meanwhile
-                mu, sigma, _ = self.encode_forward(sx, save=False)
+            try:
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):   # loader threads may issue copies meanwhile
+                    mu, sigma, _ = self.encode_forward(sx, save=False)
+            except Exception as ex:   # eager from here on
+                import warnings
+                warnings.warn(f"HIP-graph capture of the inference encode failed ({ex!r}); continuing with eager launches")
+                self.encode_graphs = False
+                torch.cuda.synchronize()
+                return None
             ent = self._enc_graphs[key] = (g, sx, mu, sigma)
         g, sx, mu, sigma = ent
         sx.copy_(x)
@@ -803,8 +810,15 @@ class Engine:
                 self.decode_forward(sz, save=False)
             cur.wait_stream(side)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):   # loader threads may issue copies meanwhile
-                recon, _ = self.decode_forward(sz, save=False)
+            try:
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):   # loader threads may issue copies meanwhile
+                    recon, _ = self.decode_forward(sz, save=False)
+            except Exception as ex:   # eager from here on
+                import warnings
+                warnings.warn(f"HIP-graph capture of the inference decode failed ({ex!r}); continuing with eager launches")
+                self.encode_graphs = False
+                torch.cuda.synchronize()
+                return None
             ent = self._dec_graphs[key] = (g, sz, recon)
         g, sz, recon = ent
         sz.copy_(z)

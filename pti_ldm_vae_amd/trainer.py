@@ -289,8 +289,15 @@ class VAETrainer:
                                dtype=torch.float32, device=images.device)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):   # loader threads may issue copies meanwhile
-                out2 = self._plain_fwd_bwd(gx, geps)
+            try:
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):   # loader threads may issue copies meanwhile
+                    out2 = self._plain_fwd_bwd(gx, geps)
+            except Exception as ex:   # a capture that fails must not take the run down: eager from here on
+                import warnings
+                warnings.warn(f"HIP-graph capture of the training step failed ({ex!r}); continuing with eager launches")
+                self.step_graph = False
+                torch.cuda.synchronize()
+                return None
             st = self._graphs[key] = (g, gx, geps, out2)
         g, gx, geps, out2 = st
         gx.copy_(images)
