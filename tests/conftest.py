@@ -18,6 +18,7 @@ def pytest_configure(config):
 # background beside the other tests (3 processes on the card in total).  torch.cuda.device_count() does not initialise
 # the GPU on this image.
 _DP_JOB = {}
+_RCCL_JOB = {}
 
 
 def _gpu_tests_selected(config):
@@ -52,12 +53,24 @@ def pytest_collection_finish(session):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "dp_gpu_worker.py"), outdir]
     _DP_JOB.update(proc=subprocess.Popen(cmd, stdout=log, stderr=subprocess.STDOUT, env=env, cwd=ROOT), outdir=outdir, log=log)
+    # the single-rank job on the REAL backend (nccl = RCCL): tests/rccl_one_rank_worker.py
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port2 = s.getsockname()[1]
+    s.close()
+    outdir2 = tempfile.mkdtemp(prefix="pti_rccl_job_")
+    log2 = open(os.path.join(outdir2, "job.log"), "w")
+    env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port2))
+    cmd2 = [sys.executable, os.path.join(ROOT, "tests", "rccl_one_rank_worker.py"), outdir2]
+    _RCCL_JOB.update(proc=subprocess.Popen(cmd2, stdout=log2, stderr=subprocess.STDOUT, env=env2, cwd=ROOT), outdir=outdir2,
+                     log=log2)
 
 
 def pytest_sessionfinish(session, exitstatus):
-    proc = _DP_JOB.get("proc")
-    if proc is not None and proc.poll() is None:
-        proc.terminate()          # the exact process started above
+    for job in (_DP_JOB, _RCCL_JOB):
+        proc = job.get("proc")
+        if proc is not None and proc.poll() is None:
+            proc.terminate()          # the exact process started above
 
 
 @pytest.fixture(scope="session")
@@ -76,6 +89,25 @@ def dp_job():
         if rc != 0:
             pytest.fail("two-rank data-parallel job failed:\n" + open(os.path.join(_DP_JOB["outdir"], "job.log")).read()[-4000:])
         return _DP_JOB["outdir"]
+    return wait
+
+
+@pytest.fixture(scope="session")
+def rccl_job():
+    """-> callable returning the output directory of the finished single-rank RCCL job."""
+    def wait():
+        proc = _RCCL_JOB.get("proc")
+        if proc is None:
+            pytest.skip("the RCCL job was not started (no GPU at session start)")
+        try:
+            rc = proc.wait(timeout=600)
+        except Exception:
+            proc.terminate()
+            pytest.fail("single-rank RCCL job did not finish within 10 minutes")
+        _RCCL_JOB["log"].close()
+        if rc != 0:
+            pytest.fail("single-rank RCCL job failed:\n" + open(os.path.join(_RCCL_JOB["outdir"], "job.log")).read()[-4000:])
+        return _RCCL_JOB["outdir"]
     return wait
 
 

@@ -90,3 +90,22 @@ def test_two_rank_adversarial_step_equals_single_rank_full_batch(dev, dp_job):
     assert rel_d <= 2e-3 and rel_g <= 2e-3
     assert dmax <= 2.5 * 2 * W.LR
     assert 0.5 * (r0["adv"]["adv_disc"] + r1["adv"]["adv_disc"]) == pytest.approx(out["adv_disc"].item(), rel=1e-3)
+
+
+def test_rccl_backend_exchange_single_rank(dev, rccl_job):
+    """The exchange path on the REAL backend of the multi-GPU run (nccl = RCCL), one rank (tests/rccl_one_rank_worker.py):
+    the bucketed all-reduces are launched from the engine's callbacks behind the side stream and joined before Adam; with
+    one rank SUM is the identity, so the gradient arena must be bit-identical to the same callback-driven step without a
+    collective behind it (and within fp32 summation order of the plain, batched step)."""
+    outdir = rccl_job()
+    r = json.load(open(os.path.join(outdir, "rccl.json")))
+    print("[rccl x1]", {k: v for k, v in r.items() if not k.startswith("launched")}, "buckets", len(r["launched"]))
+    assert r["backend"] == "nccl"
+    assert r["grads_bit_equal"] and r["n_diff"] == 0 and r["params_finite"]
+    assert r["plain_vs_callback_rel"] <= 1e-6
+    assert r["loss_plain"] == r["loss_forced"]
+    spans = [tuple(s) for s in r["launched"]]
+    assert spans[0][0] == 0 and spans[-1][1] == r["arena_len"] and len(spans) >= 4
+    assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    assert r["launched2"] == r["launched"]
+    assert r["loss_step2"] < r["loss_plain"] * 1.5      # the second step ran on updated parameters and stayed sane
