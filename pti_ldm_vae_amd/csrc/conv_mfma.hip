@@ -376,6 +376,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
 //  * PXF = 2 at 3-4 workgroups/CU, weight ring 3/6/9 deep: all within +-3 %.  A start delay for every other
 //    workgroup: slower.  64-channel chunks with the next chunk's halo prefetched into registers under the current
 //    chunk's MFMAs (246-253 VGPRs): no gain.  Next: persistent workgroups with cross-tile halo prefetch.
+//  * (round 2) the 32^2 maps at batch 32 are only 256 workgroups of 128 pixels (one per CU, 21-23 us per launch):
+//    re-tiling those launches with PXF = 2 (512 workgroups of 64 pixels, no spills, 3 resident per CU) left the
+//    training step unchanged (12.04 vs 12.04 ms, same box), so it is not in.
 // =============================================================================================
 __host__ __device__ constexpr int pick_ck2(int cin, int ct) {
   const int ck = cin % 128 == 0 ? 128 : (cin % 64 == 0 ? 64 : 32);
