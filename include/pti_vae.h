@@ -28,7 +28,7 @@ extern "C" {
 
 typedef void* pti_stream_t; /* hipStream_t */
 
-#define PTI_ABI_VERSION 3
+#define PTI_ABI_VERSION 4
 
 #define PTI_OK 0
 #define PTI_EINVAL (-1)   /* bad pointer / dimension */
@@ -342,6 +342,22 @@ int pti_pd_final_dgrad(const float* d_logits, const void* y_prev, const float* n
 int pti_pd_final_wgrad_blocks(int n, int h, int w_);
 int pti_pd_final_wgrad(const float* d_logits, const void* y_prev, const float* norm, float* partials, int n, int h,
                        int w_, int c, float slope, pti_stream_t s);
+
+/* ---- LPIPS comparison tail of the perceptual term ----------------------------------------------------
+ * Reference: vae_scripts/train_vae.py:299, :395-397 (monai.losses.PerceptualLoss(spatial_dims=2, network_type="squeeze")
+ * = lpips.LPIPS(net="squeeze"): per feature tap normalize_tensor on both maps, squared difference, the 1x1 `lin` layer,
+ * spatial mean).  a, b: fp32 NCHW feature maps [n][c][hw] of the reconstruction / the target, w: fp32 [c] (the lin
+ * layer's weight).  The feature network itself stays torch ops (models/perceptual.py); this is its memory-bound tail.
+ *   fwd: partials float [n][pti_lpips_tap_blocks(c, hw)] -- per-workgroup sums of sum_c w_c (a_c/(|a|+1e-10) -
+ *        b_c/(|b|+1e-10))^2 over their pixels; the tap's value for sample i is sum(partials[i][:]) / hw.
+ *        saved float [n][3][hw] = {|a_p|, |b_p|, sum_c w_c d_c a_c}: what the backward needs per pixel.
+ *   bwd: ga [n][c][hw] = gout[i] * d value_i / d a   (gout fp32 [n]); b and w get no gradient (frozen network, target).
+ * No atomics: bitwise reproducible.                                                                                   */
+int pti_lpips_tap_blocks(int c, int hw);
+int pti_lpips_tap_fwd(const float* a, const float* b, const float* w, float* saved, float* partials, int n, int c, int hw,
+                      pti_stream_t s);
+int pti_lpips_tap_bwd(const float* a, const float* b, const float* w, const float* saved, const float* gout, float* ga,
+                      int n, int c, int hw, pti_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PTI_VAE_LIB") or os.path.join(_HERE, "libpti_vae_hip.so")   # env: kernel-variant A/B runs
 
-ABI_VERSION = 3   # PTI_ABI_VERSION of include/pti_vae.h
+ABI_VERSION = 4   # PTI_ABI_VERSION of include/pti_vae.h
 PTI_CONV_S1, PTI_CONV_S2PAD, PTI_CONV_UP2, PTI_CONV_ZINS = 0, 1, 2, 3
 PTI_PRO_NONE, PTI_PRO_GN, PTI_PRO_GN_SILU = 0, 1, 2
 
@@ -96,6 +96,9 @@ SIGNATURES = {
     "pti_pd_final_dgrad": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "pti_pd_final_wgrad_blocks": (_I, [_I, _I, _I]),
     "pti_pd_final_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "pti_lpips_tap_blocks": (_I, [_I, _I]),
+    "pti_lpips_tap_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "pti_lpips_tap_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "pti_adam_step": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I, _F, _P]),
     "pti_preprocess_batch": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "pti_cast_nchw_f32_to_nhwc_bf16": (_I, [_P, _P, _I, _I, _I, _P]),

@@ -8,10 +8,13 @@ weight 1.0 in every shipped config.
 Status here: the pretrained weights (torchvision ``squeezenet1_1`` + lpips ``squeeze.pth``) cannot be fetched — there is
 no network — and neither ``lpips`` nor ``torchvision`` is installed, so the network is RESTATED below in plain torch with
 the two packages' ``state_dict`` key names, and ``PerceptualLoss(weights=(backbone_file, lin_file))`` loads files the
-user supplies locally (``torch.load(..., weights_only=True)``).  The network runs as ordinary torch ops on the HIP device
-(it is a fixed feature extractor next to the hot path, 2 % of the parameters; hand-written kernels would buy little and
-could not be checked against real weights here); its gradient w.r.t. the reconstruction is taken by autograd and ADDED to
-the native step's ``d_recon`` (``VAETrainer(perceptual=...)``), so the VAE itself still runs on the HIP engine.
+user supplies locally (``torch.load(..., weights_only=True)``).  The feature network runs as ordinary torch ops on the HIP
+device (a fixed extractor next to the hot path, 2 % of the parameters; its convolutions could not be checked against real
+weights here); the memory-bound comparison tail of every tap -- normalise both maps, squared difference, ``lin`` layer,
+spatial mean, and its backward -- is two hand-written HIP kernels on the device (``csrc/lpips.hip``,
+``pti_lpips_tap_fwd`` / ``_bwd``: 2.9 -> 0.4 ms of the term at batch 32), the torch formula below being what CPU tensors
+take (the tests' checker).  The gradient w.r.t. the reconstruction is taken by autograd and ADDED to the native step's
+``d_recon`` (``VAETrainer(perceptual=...)``), so the VAE itself still runs on the HIP engine.
 Parity: UNPINNED (restated from the published structure of both packages; no weights, no reference output available).
 Without supplied weights the class refuses to build unless ``allow_random_init=True`` (tests, throughput runs).
 """
@@ -70,12 +73,39 @@ class _Lin(nn.Module):
         return self.model(x)
 
 
+class _LpipsTapFn(torch.autograd.Function):
+    """One tap's comparison on the device: (a, b, w) -> value [N]; gradient to ``a`` only (``b`` is the target's map, ``w``
+    a frozen weight).  HIP kernels behind ``ops.lpips_tap_fwd`` / ``ops.lpips_tap_bwd``."""
+
+    @staticmethod
+    def forward(ctx, a, b, w):
+        from .. import ops
+        a, b, w = a.contiguous(), b.contiguous(), w.contiguous()
+        val, saved = ops.lpips_tap_fwd(a, b, w)
+        ctx.save_for_backward(a, b, w, saved)
+        return val
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import ops
+        a, b, w, saved = ctx.saved_tensors
+        return ops.lpips_tap_bwd(a, b, w, saved, g.contiguous().float()), None, None
+
+
+def lpips_tap_torch(a, b, lin_weight):
+    """The tap comparison as torch ops (lpips' normalize_tensor, squared difference, lin layer, spatial mean) -> [N]."""
+    a = a / (a.pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
+    b = b / (b.pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
+    return F.conv2d((a - b) ** 2, lin_weight).mean((2, 3)).view(-1)
+
+
 class SqueezeLPIPS(nn.Module):
     """``lpips.LPIPS(net="squeeze", lpips=True, spatial=False)`` in eval mode: input scaling, seven SqueezeNet-1.1
     feature taps (``features[0:2], [2:5], [5:8], [8:10], [10:11], [11:12], [12:13]``), channel-unit-normalised squared
     differences weighted by the ``lin`` layers, spatially averaged and summed.  Returns [N,1,1,1]."""
 
     SLICES = ((0, 2), (2, 5), (5, 8), (8, 10), (10, 11), (11, 12), (12, 13))
+    fused_tail = True      # device tensors take the HIP tail kernels (False: torch ops everywhere; A/B and tests)
 
     def __init__(self):
         super().__init__()
@@ -101,10 +131,12 @@ class SqueezeLPIPS(nn.Module):
         f1 = self._taps((in1 - self.shift) / self.scale)
         total = 0.0
         for k, (a, b) in enumerate(zip(f0, f1)):
-            a = a / (a.pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
-            b = b / (b.pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
-            total = total + getattr(self, f"lin{k}")((a - b) ** 2).mean((2, 3), keepdim=True)
-        return total
+            w = getattr(self, f"lin{k}").model[1].weight
+            if a.is_cuda and a.dtype == torch.float32 and self.fused_tail:
+                total = total + _LpipsTapFn.apply(a, b, w.view(-1))
+            else:
+                total = total + lpips_tap_torch(a, b, w)
+        return total.view(-1, 1, 1, 1)
 
     # ---- local weight files ------------------------------------------------------------------------------------------
     def load_local_weights(self, backbone_file: str, lin_file: str) -> None:

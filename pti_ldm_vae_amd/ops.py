@@ -794,3 +794,37 @@ def pd_final_wgrad(d_logits, y_prev, norm, *, slope=0.2):
     out = torch.empty(row, dtype=F32, device=y_prev.device)
     L.check(L.lib().pti_gn_sums_finalize(_ptr(part), _ptr(out), 1, blocks, row, _stream()), "pti_gn_sums_finalize")
     return out
+
+
+# ---- LPIPS comparison tail (perceptual term) -------------------------------------------------------------
+def lpips_tap_fwd(a, b, w):
+    """a, b: fp32 NCHW feature maps [n, c, h, w_] (contiguous), w: fp32 [c] -> (value [n], saved [n, 3, h*w_]):
+    value_i = mean_p sum_c w_c (a_c/(|a_p|+1e-10) - b_c/(|b_p|+1e-10))^2 (lpips normalize_tensor + lin layer + spatial mean)."""
+    _chk(a, F32, "a", 4)
+    _chk(b, F32, "b", 4)
+    _chk(w, F32, "w", 1)
+    if a.shape != b.shape or w.numel() != a.shape[1]:
+        raise ValueError("lpips_tap_fwd: shapes")
+    n, c, h, ww = a.shape
+    hw = h * ww
+    blocks = L.lib().pti_lpips_tap_blocks(c, hw)
+    if blocks <= 0:
+        raise ValueError("lpips_tap_fwd: empty feature map")
+    saved = torch.empty(n, 3, hw, dtype=F32, device=a.device)
+    part = torch.empty(n, blocks, dtype=F32, device=a.device)
+    L.check(L.lib().pti_lpips_tap_fwd(_ptr(a), _ptr(b), _ptr(w), _ptr(saved), _ptr(part), n, c, hw, _stream()), "pti_lpips_tap_fwd")
+    return part.sum(1) / hw, saved
+
+
+def lpips_tap_bwd(a, b, w, saved, gout):
+    """-> d(sum_i gout_i * value_i) / d a, fp32 like a."""
+    _chk(a, F32, "a", 4)
+    _chk(b, F32, "b", 4)
+    _chk(gout, F32, "gout", 1)
+    n, c, h, ww = a.shape
+    if a.shape != b.shape or tuple(saved.shape) != (n, 3, h * ww) or gout.numel() != n or w.numel() != c:
+        raise ValueError("lpips_tap_bwd: shapes")
+    ga = torch.empty_like(a)
+    L.check(L.lib().pti_lpips_tap_bwd(_ptr(a), _ptr(b), _ptr(w), _ptr(saved), _ptr(gout), _ptr(ga), n, c, h * ww, _stream()),
+            "pti_lpips_tap_bwd")
+    return ga

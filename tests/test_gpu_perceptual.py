@@ -1,0 +1,111 @@
+"""GPU tests of the LPIPS comparison tail kernels (csrc/lpips.hip; reference: train_vae.py:299,:395-397 ->
+monai PerceptualLoss("squeeze") -> lpips normalize_tensor / squared difference / lin layer / spatial mean).
+
+The checker is the same formula as torch ops in float64 on the CPU (``lpips_tap_torch``: what the module itself runs
+for CPU tensors).  Tolerances: the kernels compute in fp32 with a different summation order than torch -> value 1e-5
+relative, gradient rel-L2 1e-5.  Parity of the whole term vs the reference stays UNPINNED (no weights, see
+models/perceptual.py); these tests pin the kernels to the published formula."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+# (n, c, h, w): every tap shape class of SqueezeNet-1.1 at 256^2 input (odd map sizes, 1/2/4/8 channel slices) + ragged
+SHAPES = [(2, 64, 127, 127), (3, 128, 63, 63), (2, 256, 31, 31), (4, 384, 15, 15), (2, 512, 15, 15), (1, 48, 5, 7),
+          (2, 100, 9, 9), (1, 8, 1, 1)]
+
+
+def _inputs(shape, seed, relu=True):
+    g = torch.Generator().manual_seed(seed)
+    n, c, h, w = shape
+    a = torch.randn(n, c, h, w, generator=g)
+    b = a + 0.3 * torch.randn(n, c, h, w, generator=g)
+    if relu:
+        a, b = a.relu(), b.relu()
+    wt = torch.rand(c, generator=g) * 0.2
+    return a, b, wt
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_tap_forward_and_gradient_vs_torch_float64(dev, shape):
+    from pti_ldm_vae_amd.models.perceptual import _LpipsTapFn, lpips_tap_torch
+    a, b, wt = _inputs(shape, seed=sum(shape))
+    a64 = a.double().requires_grad_(True)
+    v64 = lpips_tap_torch(a64, b.double(), wt.double().view(1, -1, 1, 1))
+    gout = torch.linspace(0.5, 1.5, shape[0], dtype=torch.float64)
+    g64, = torch.autograd.grad((v64 * gout).sum(), a64)
+    ad = a.to(dev).requires_grad_(True)
+    v = _LpipsTapFn.apply(ad, b.to(dev), wt.to(dev))
+    gd, = torch.autograd.grad((v * gout.float().to(dev)).sum(), ad)
+    torch.cuda.synchronize()
+    relv = ((v.cpu().double() - v64).abs() / v64.abs().clamp_min(1e-12)).max().item()
+    relg = ((gd.cpu().double() - g64).norm() / g64.norm()).item()
+    print(f"[lpips tap {shape}] value rel {relv:.2e}, grad relL2 {relg:.2e}")
+    assert relv <= 1e-5 and relg <= 1e-5
+    assert torch.isfinite(gd).all()
+
+
+def test_tap_is_zero_on_identical_maps_and_bitwise_reproducible(dev):
+    from pti_ldm_vae_amd import ops
+    a, b, wt = _inputs((3, 128, 63, 63), seed=5)
+    a, b, wt = a.to(dev), b.to(dev), wt.to(dev)
+    v0, _ = ops.lpips_tap_fwd(a, a.clone(), wt)
+    assert float(v0.abs().max()) == 0.0
+    v1, s1 = ops.lpips_tap_fwd(a, b, wt)
+    v2, s2 = ops.lpips_tap_fwd(a, b, wt)
+    g = torch.ones(3, device=dev)
+    assert torch.equal(v1, v2) and torch.equal(s1, s2)
+    assert torch.equal(ops.lpips_tap_bwd(a, b, wt, s1, g), ops.lpips_tap_bwd(a, b, wt, s2, g))
+
+
+def test_all_zero_pixels_give_finite_gradients(dev):
+    """A pixel whose features are all zero after ReLU: torch's autograd formula yields 0/0 = NaN there; the kernel keeps
+    the finite first term (documented in csrc/lpips.hip).  Everywhere else the two agree."""
+    from pti_ldm_vae_amd.models.perceptual import _LpipsTapFn, lpips_tap_torch
+    a, b, wt = _inputs((2, 64, 9, 9), seed=9)
+    a[:, :, 4, 4] = 0.0
+    a64 = a.double().requires_grad_(True)
+    g64, = torch.autograd.grad(lpips_tap_torch(a64, b.double(), wt.double().view(1, -1, 1, 1)).sum(), a64)
+    assert torch.isnan(g64[:, :, 4, 4]).all()          # the behaviour being documented
+    ad = a.to(dev).requires_grad_(True)
+    gd, = torch.autograd.grad(_LpipsTapFn.apply(ad, b.to(dev), wt.to(dev)).sum(), ad)
+    assert torch.isfinite(gd).all()
+    mask = torch.ones_like(a, dtype=torch.bool)
+    mask[:, :, 4, 4] = False
+    rel = ((gd.cpu().double()[mask] - g64[mask]).norm() / g64[mask].norm()).item()
+    assert rel <= 1e-5
+
+
+def test_bad_arguments_are_refused(dev):
+    from pti_ldm_vae_amd import ops
+    a = torch.zeros(2, 16, 4, 4, device=dev)
+    with pytest.raises((ValueError, TypeError)):
+        ops.lpips_tap_fwd(a, torch.zeros(2, 16, 4, 5, device=dev), torch.zeros(16, device=dev))
+    with pytest.raises((ValueError, TypeError)):
+        ops.lpips_tap_fwd(a, a, torch.zeros(8, device=dev))
+    with pytest.raises((ValueError, TypeError)):
+        ops.lpips_tap_fwd(a.half(), a.half(), torch.zeros(16, device=dev))
+    with pytest.raises((ValueError, TypeError)):
+        ops.lpips_tap_fwd(a.cpu(), a.cpu(), torch.zeros(16))
+
+
+def test_whole_term_fused_tail_equals_torch_tail(dev):
+    """SqueezeLPIPS on the device with the HIP tail vs the same module with ``fused_tail = False`` (torch ops end to end):
+    value and gradient w.r.t. the reconstruction, 256x256 inputs (all seven taps at their real sizes)."""
+    import copy
+    from pti_ldm_vae_amd.models import PerceptualLoss
+    torch.manual_seed(3)
+    pl = PerceptualLoss(allow_random_init=True).to(dev)
+    ref = copy.deepcopy(pl)
+    ref.net.fused_tail = False
+    g = torch.Generator().manual_seed(4)
+    y = torch.rand(3, 1, 256, 256, generator=g).to(dev)
+    x = (y + 0.1 * torch.randn(3, 1, 256, 256, generator=g).to(dev)).requires_grad_(True)
+    l1 = pl(x, y)
+    g1, = torch.autograd.grad(l1, x)
+    l2 = ref(x, y)
+    g2, = torch.autograd.grad(l2, x)
+    rel = ((g1 - g2).norm() / g2.norm()).item()
+    print(f"[lpips term] fused {l1.item():.6e} vs torch {l2.item():.6e}; grad relL2 {rel:.2e}")
+    assert l1.item() == pytest.approx(l2.item(), rel=1e-5)
+    assert rel <= 1e-4
