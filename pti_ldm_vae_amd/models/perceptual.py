@@ -126,9 +126,15 @@ class SqueezeLPIPS(nn.Module):
             out.append(x)
         return out
 
+    def taps(self, x):
+        """Input scaling + the seven feature taps of a 3-channel image batch."""
+        return self._taps((x - self.shift) / self.scale)
+
     def forward(self, in0, in1):
-        f0 = self._taps((in0 - self.shift) / self.scale)
-        f1 = self._taps((in1 - self.shift) / self.scale)
+        return self.compare(self.taps(in0), self.taps(in1))
+
+    def compare(self, f0, f1):
+        """LPIPS from two sets of taps -> [N,1,1,1] (gradients flow to ``f0`` only through the device kernels)."""
         total = 0.0
         for k, (a, b) in enumerate(zip(f0, f1)):
             w = getattr(self, f"lin{k}").model[1].weight
@@ -178,3 +184,13 @@ class PerceptualLoss(nn.Module):
 
     def forward(self, input: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         return self.net(ensure_three_channels(input.float()), ensure_three_channels(target.float())).mean()
+
+    @torch.no_grad()
+    def target_taps(self, target: torch.Tensor):
+        """The target's feature taps alone (no autograd graph): they do not depend on the reconstruction, so the trainer
+        computes them on its side stream while the VAE forward runs, and hands them to ``from_taps``."""
+        return self.net.taps(ensure_three_channels(target.float()))
+
+    def from_taps(self, input: torch.Tensor, target_taps) -> torch.Tensor:
+        """``forward(input, target)`` with the target's taps precomputed by ``target_taps(target)``."""
+        return self.net.compare(self.net.taps(ensure_three_channels(input.float())), target_taps).mean()

@@ -238,16 +238,38 @@ class VAETrainer:
             self.opt_d.step(grad_scale=1.0 / self.world)
         return 0.5 * (l_fake + l_real)
 
-    def _perceptual_term(self, recon, images, d_recon):
+    def _perceptual_target_taps(self, images):
+        """The target half of the perceptual term does not depend on the reconstruction: enqueue it on the side stream
+        (idle during the VAE forward) at the start of the step.  -> (taps, event) or None (no side stream / module
+        without the split API)."""
+        side = self.eng.wgrad_stream
+        if side is None or not hasattr(self.perceptual, "target_taps"):
+            return None
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)                       # the images were produced on the main stream
+        with torch.cuda.stream(side):
+            taps = self.perceptual.target_taps(images)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        for t in taps:                               # allocated on the side stream, read on the main one
+            t.record_stream(main)
+        return taps, ev
+
+    def _perceptual_term(self, recon, images, d_recon, target=None):
         """train_vae.py:395-397: p_loss = loss_perceptual(ensure_three_channels(recon), ensure_three_channels(images));
-        adds perceptual_weight * d p_loss / d recon into ``d_recon`` (when given)."""
+        adds perceptual_weight * d p_loss / d recon into ``d_recon`` (when given).  ``target``: what
+        ``_perceptual_target_taps(images)`` returned at the start of the step."""
         from .utils.losses import ensure_three_channels
         if d_recon is None:
             with torch.no_grad():
                 return self.perceptual(ensure_three_channels(recon.float()), ensure_three_channels(images.float()))
         r = recon.detach().requires_grad_(True)
         with torch.enable_grad():
-            p = self.perceptual(ensure_three_channels(r.float()), ensure_three_channels(images.float()))
+            if target is not None:
+                torch.cuda.current_stream().wait_event(target[1])
+                p = self.perceptual.from_taps(ensure_three_channels(r.float()), target[0])
+            else:
+                p = self.perceptual(ensure_three_channels(r.float()), ensure_three_channels(images.float()))
             (g,) = torch.autograd.grad(p, r)
         d_recon.add_(g, alpha=self.perceptual_weight)
         return p.detach()
@@ -338,6 +360,9 @@ class VAETrainer:
         red.begin_step()
         eng.grad_ready_cb = red.ready if self.world > 1 else None
         try:
+            p_target = None
+            if self.perceptual is not None and self.perceptual_weight != 0.0:
+                p_target = self._perceptual_target_taps(images)     # side stream, under the VAE forward
             mu, sigma, c_enc = eng.encode_forward(images, save=True)
             if eps is None:
                 eps = torch.randn(sigma.shape, generator=self.gen, device=sigma.device, dtype=sigma.dtype)
@@ -353,7 +378,7 @@ class VAETrainer:
                 ar_out = self._ar_term(mu, attributes, d_mu)
             p_loss = None
             if self.perceptual is not None and self.perceptual_weight != 0.0:
-                p_loss = self._perceptual_term(recon, images, d_recon)
+                p_loss = self._perceptual_term(recon, images, d_recon, p_target)
             adv_ctx = None
             if adversarial:           # + adv_weight * generator term: its gradient w.r.t. the reconstruction joins d_recon
                 adv_gen, adv_ctx = self._adv_generator_term(recon, d_recon)
