@@ -359,6 +359,22 @@ int pti_lpips_tap_fwd(const float* a, const float* b, const float* w, float* sav
 int pti_lpips_tap_bwd(const float* a, const float* b, const float* w, const float* saved, const float* gout, float* ga,
                       int n, int c, int hw, pti_stream_t s);
 
+/* ---- trunk of the perceptual network: the passes between its convolutions ---------------------------
+ * Reference: torchvision squeezenet1_1.features under lpips.LPIPS(net="squeeze") (train_vae.py:299): Fire modules and
+ * MaxPool2d(kernel 3, stride 2, ceil_mode=True).  The Fire convolutions run on pti_conv2d_mfma (fp16 forward, bf16
+ * data gradient); activations NHWC fp16, gradients NHWC bf16, element counts / channels multiples of 8.
+ *   pti_relu_f16:        x = max(x, 0) in place.
+ *   pti_relu_bwd:        g = y > 0 ? g : 0 in place (y = the ReLU OUTPUT).
+ *   pti_maxpool3s2_out:  pooled size of one spatial dimension.
+ *   pti_maxpool3s2_fwd:  y [n][ho][wo][c] = max over the (clipped) 3x3 windows of x [n][h][w][c].
+ *   pti_maxpool3s2_bwd:  gx (+)= gather of gy over the windows whose maximum the element is (no atomics).             */
+int pti_relu_f16(void* x, int64_t count, pti_stream_t s);
+int pti_relu_bwd(void* g, const void* y, int64_t count, pti_stream_t s);
+int pti_maxpool3s2_out(int h);
+int pti_maxpool3s2_fwd(const void* x, void* y, int n, int h, int w, int c, pti_stream_t s);
+int pti_maxpool3s2_bwd(const void* gy, const void* x, const void* y, void* gx, int n, int h, int w, int c, int accumulate,
+                       pti_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,149 @@
+// Element-wise / pooling passes of the perceptual network's trunk ("HIP convs reused from K1").
+// Reference: vae_scripts/train_vae.py:299 -> monai PerceptualLoss("squeeze") -> lpips.LPIPS(net="squeeze") ->
+// torchvision squeezenet1_1.features: Fire modules (1x1 squeeze + ReLU, 1x1 and 3x3 expands + ReLU, concatenated) and
+// MaxPool2d(3, stride 2, ceil_mode=True).  The convolutions of the Fire modules run on pti_conv2d_mfma (the two expands
+// as ONE 3x3 convolution whose first half holds the 1x1 weights at the centre tap, so the concatenation is free); the
+// passes here are what is left between them.  Activations: NHWC fp16 (forward), gradients: NHWC bf16; 8 channels
+// (16 bytes) per thread; no atomics (the pooling backward GATHERS), bitwise reproducible.
+#include "pti_common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256) void relu_f16_kernel(u32x4* __restrict__ x, long long n8) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  f16x8 v = __builtin_bit_cast(f16x8, x[i]);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = v[j] > (_Float16)0 ? v[j] : (_Float16)0;
+  x[i] = __builtin_bit_cast(u32x4, v);
+}
+
+// g = y > 0 ? g : 0   (g bf16, y the fp16 ReLU OUTPUT)
+__global__ __launch_bounds__(256) void relu_bwd_kernel(u32x4* __restrict__ g, const u32x4* __restrict__ y, long long n8) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const f16x8 yv = __builtin_bit_cast(f16x8, y[i]);
+  u32x4 gv = g[i];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    uint32_t w = gv[j];
+    if (!(yv[2 * j] > (_Float16)0)) w &= 0xffff0000u;
+    if (!(yv[2 * j + 1] > (_Float16)0)) w &= 0x0000ffffu;
+    gv[j] = w;
+  }
+  g[i] = gv;
+}
+
+// MaxPool2d(3, 2, ceil_mode=True) on NHWC fp16: thread = (output pixel, 8-channel piece); windows are clipped to the map
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ y, int H,
+                                                          int W, int Ho, int Wo, int NC, long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int pc = (int)(i % NC);
+  long long r = i / NC;
+  const int ow = (int)(r % Wo); r /= Wo;
+  const int oh = (int)(r % Ho);
+  const long long n = r / Ho;
+  f16x8 m;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) m[j] = -(_Float16)65504.f;
+  for (int dh = 0; dh < 3; ++dh) {
+    const int h = 2 * oh + dh;
+    if (h >= H) break;
+    for (int dw = 0; dw < 3; ++dw) {
+      const int w = 2 * ow + dw;
+      if (w >= W) break;
+      const f16x8 v = __builtin_bit_cast(f16x8, x[((n * H + h) * W + w) * NC + pc]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m[j] = v[j] > m[j] ? v[j] : m[j];
+    }
+  }
+  y[i] = __builtin_bit_cast(u32x4, m);
+}
+
+// gx[h][w] (+)= sum over the <= 4 windows (oh, ow) that contain (h, w) of gy[oh][ow] where x[h][w] == y[oh][ow]
+// (the gradient goes to the maximum; ties -- which for these post-ReLU maps happen at 0 only, where the ReLU backward
+// that follows zeroes the gradient anyway -- share it).  Thread = (input pixel, 8-channel piece).
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const u32x4* __restrict__ gy, const u32x4* __restrict__ x,
+                                                          const u32x4* __restrict__ y, u32x4* __restrict__ gx, int H,
+                                                          int W, int Ho, int Wo, int NC, long long total, int accumulate) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int pc = (int)(i % NC);
+  long long r = i / NC;
+  const int w = (int)(r % W); r /= W;
+  const int h = (int)(r % H);
+  const long long n = r / H;
+  const f16x8 xv = __builtin_bit_cast(f16x8, x[i]);
+  float acc[8];
+  if (accumulate) unpack8(gx[i], acc);
+  else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  }
+  const int oh1 = min(h >> 1, Ho - 1), oh0 = max((h - 1) >> 1, 0);   // windows with 2*oh <= h <= 2*oh + 2
+  const int ow1 = min(w >> 1, Wo - 1), ow0 = max((w - 1) >> 1, 0);
+  for (int oh = oh0; oh <= oh1; ++oh)
+    for (int ow = ow0; ow <= ow1; ++ow) {
+      const long long o = ((n * Ho + oh) * Wo + ow) * NC + pc;
+      const f16x8 yv = __builtin_bit_cast(f16x8, y[o]);
+      float g[8];
+      unpack8(gy[o], g);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (xv[j] == yv[j]) acc[j] += g[j];
+    }
+  gx[i] = pack8(acc);
+}
+
+inline int pool_out(int h) {
+  int ho = (h - 3 + 1) / 2 + 1;          // ceil((h - 3) / 2) + 1
+  if (h < 3) ho = 1;
+  if ((ho - 1) * 2 >= h) --ho;           // the last window must start inside the map (torch's rule)
+  return ho;
+}
+
+}  // namespace
+
+extern "C" int pti_relu_f16(void* x, int64_t count, pti_stream_t s) {
+  if (!x || count <= 0 || count % 8) PTI_FAIL(PTI_EINVAL, "relu_f16: count %lld must be a positive multiple of 8", (long long)count);
+  const long long n8 = count / 8;
+  PTI_LAUNCH(relu_f16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)s, (u32x4*)x, n8);
+  PTI_CHECK_LAUNCH("relu_f16");
+  return PTI_OK;
+}
+
+extern "C" int pti_relu_bwd(void* g, const void* y, int64_t count, pti_stream_t s) {
+  if (!g || !y || count <= 0 || count % 8) PTI_FAIL(PTI_EINVAL, "relu_bwd: count %lld must be a positive multiple of 8", (long long)count);
+  const long long n8 = count / 8;
+  PTI_LAUNCH(relu_bwd_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)s, (u32x4*)g,
+             (const u32x4*)y, n8);
+  PTI_CHECK_LAUNCH("relu_bwd");
+  return PTI_OK;
+}
+
+extern "C" int pti_maxpool3s2_out(int h) { return h > 0 ? pool_out(h) : 0; }
+
+extern "C" int pti_maxpool3s2_fwd(const void* x, void* y, int n, int h, int w, int c, pti_stream_t s) {
+  if (!x || !y || n <= 0 || h <= 0 || w <= 0 || c <= 0 || c % 8) PTI_FAIL(PTI_EINVAL, "maxpool3s2_fwd: bad args (c %% 8)");
+  const int ho = pool_out(h), wo = pool_out(w), nc = c / 8;
+  const long long total = (long long)n * ho * wo * nc;
+  PTI_LAUNCH(maxpool_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, (const u32x4*)x,
+             (u32x4*)y, h, w, ho, wo, nc, total);
+  PTI_CHECK_LAUNCH("maxpool3s2_fwd");
+  return PTI_OK;
+}
+
+extern "C" int pti_maxpool3s2_bwd(const void* gy, const void* x, const void* y, void* gx, int n, int h, int w, int c,
+                                  int accumulate, pti_stream_t s) {
+  if (!gy || !x || !y || !gx || n <= 0 || h <= 0 || w <= 0 || c <= 0 || c % 8)
+    PTI_FAIL(PTI_EINVAL, "maxpool3s2_bwd: bad args (c %% 8)");
+  const int ho = pool_out(h), wo = pool_out(w), nc = c / 8;
+  const long long total = (long long)n * h * w * nc;
+  PTI_LAUNCH(maxpool_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, (const u32x4*)gy,
+             (const u32x4*)x, (const u32x4*)y, (u32x4*)gx, h, w, ho, wo, nc, total, accumulate);
+  PTI_CHECK_LAUNCH("maxpool3s2_bwd");
+  return PTI_OK;
+}

@@ -92,6 +92,36 @@ class _LpipsTapFn(torch.autograd.Function):
         return ops.lpips_tap_bwd(a, b, w, saved, g.contiguous().float()), None, None
 
 
+class _TrunkCompareFn(torch.autograd.Function):
+    """LPIPS value [N] from tap 0 of the reconstruction (NCHW fp32, output of the torch first layer) and the target's
+    seven taps, with the rest of the feature network on the HIP trunk (``perceptual_engine.SqueezeTrunk``) and the
+    comparison on the tail kernels; gradient to tap 0 only."""
+
+    @staticmethod
+    def forward(ctx, t0, trunk, target, lin_ws):
+        from .. import ops
+        t0 = t0.contiguous()
+        taps, saved = trunk.forward(trunk.to_nhwc_f16(t0), save=True)
+        feats = [t0] + [trunk.to_nchw_f32(t) for t in taps]
+        total, tails = None, []
+        for a, b, w in zip(feats, target, lin_ws):
+            val, sv = ops.lpips_tap_fwd(a, b, w)
+            tails.append(sv)
+            total = val if total is None else total + val
+        ctx.trunk, ctx.saved, ctx.feats, ctx.target, ctx.lin_ws, ctx.tails = trunk, saved, feats, target, lin_ws, tails
+        return total
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import ops
+        g = g.contiguous().float()
+        gas = [ops.lpips_tap_bwd(a, b, w, sv, g) for a, b, w, sv in zip(ctx.feats, ctx.target, ctx.lin_ws, ctx.tails)]
+        trunk = ctx.trunk
+        g0 = trunk.backward(ctx.saved, [trunk.to_nhwc_bf16(x) for x in gas[1:]])
+        ctx.saved = ctx.feats = ctx.tails = None
+        return gas[0] + trunk.to_nchw_f32(g0), None, None, None
+
+
 def lpips_tap_torch(a, b, lin_weight):
     """The tap comparison as torch ops (lpips' normalize_tensor, squared difference, lin layer, spatial mean) -> [N]."""
     a = a / (a.pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
@@ -106,6 +136,8 @@ class SqueezeLPIPS(nn.Module):
 
     SLICES = ((0, 2), (2, 5), (5, 8), (8, 10), (10, 11), (11, 12), (12, 13))
     fused_tail = True      # device tensors take the HIP tail kernels (False: torch ops everywhere; A/B and tests)
+    native_trunk = True    # device tensors take the HIP trunk after the first convolution (perceptual_engine.SqueezeTrunk)
+    _trunk = None
 
     def __init__(self):
         super().__init__()
@@ -127,10 +159,39 @@ class SqueezeLPIPS(nn.Module):
         return out
 
     def taps(self, x):
-        """Input scaling + the seven feature taps of a 3-channel image batch."""
+        """Input scaling + the seven feature taps of a 3-channel image batch (torch ops)."""
         return self._taps((x - self.shift) / self.scale)
 
+    # ---- device path: first layer in torch, everything after it on the HIP library -------------------------------------
+    def use_native(self, x) -> bool:
+        return bool(self.native_trunk and self.fused_tail and x.is_cuda and x.dtype == torch.float32)
+
+    def trunk(self):
+        dev = self.features[0].weight.device
+        if self._trunk is None or self._trunk_dev != dev:
+            from ..perceptual_engine import SqueezeTrunk
+            self._trunk, self._trunk_dev = SqueezeTrunk(self), dev
+        return self._trunk
+
+    def tap0(self, x):
+        x = (x - self.shift) / self.scale
+        return self.features[1](self.features[0](x))
+
+    @torch.no_grad()
+    def native_target_taps(self, x):
+        """The seven taps of the TARGET as NCHW fp32 (what ``native_compare`` consumes), no autograd graph."""
+        tr = self.trunk()
+        t0 = self.tap0(x).contiguous()
+        taps, _ = tr.forward(tr.to_nhwc_f16(t0), save=False)
+        return [t0] + [tr.to_nchw_f32(t) for t in taps]
+
+    def native_compare(self, in0, target_taps):
+        lin_ws = [getattr(self, f"lin{k}").model[1].weight.view(-1) for k in range(len(self.SLICES))]
+        return _TrunkCompareFn.apply(self.tap0(in0), self.trunk(), target_taps, lin_ws).view(-1, 1, 1, 1)
+
     def forward(self, in0, in1):
+        if self.use_native(in0):
+            return self.native_compare(in0, self.native_target_taps(in1))
         return self.compare(self.taps(in0), self.taps(in1))
 
     def compare(self, f0, f1):
@@ -143,6 +204,10 @@ class SqueezeLPIPS(nn.Module):
             else:
                 total = total + lpips_tap_torch(a, b, w)
         return total.view(-1, 1, 1, 1)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._trunk = None          # the HIP trunk packs the weights once: rebuild it from the loaded ones
+        return super().load_state_dict(*args, **kwargs)
 
     # ---- local weight files ------------------------------------------------------------------------------------------
     def load_local_weights(self, backbone_file: str, lin_file: str) -> None:
@@ -161,6 +226,7 @@ class SqueezeLPIPS(nn.Module):
                 raise ValueError(f"perceptual weights: shape of '{k}' is {tuple(src[k].shape)}, expected {tuple(own[k].shape)}")
             picked[k] = src[k]
         self.load_state_dict(picked, strict=True)
+        self._trunk = None          # the HIP trunk packs the weights once: rebuild it from the loaded ones
 
 
 class PerceptualLoss(nn.Module):
@@ -189,8 +255,12 @@ class PerceptualLoss(nn.Module):
     def target_taps(self, target: torch.Tensor):
         """The target's feature taps alone (no autograd graph): they do not depend on the reconstruction, so the trainer
         computes them on its side stream while the VAE forward runs, and hands them to ``from_taps``."""
-        return self.net.taps(ensure_three_channels(target.float()))
+        x = ensure_three_channels(target.float())
+        return self.net.native_target_taps(x) if self.net.use_native(x) else self.net.taps(x)
 
     def from_taps(self, input: torch.Tensor, target_taps) -> torch.Tensor:
         """``forward(input, target)`` with the target's taps precomputed by ``target_taps(target)``."""
-        return self.net.compare(self.net.taps(ensure_three_channels(input.float())), target_taps).mean()
+        x = ensure_three_channels(input.float())
+        if self.net.use_native(x):
+            return self.net.native_compare(x, target_taps).mean()
+        return self.net.compare(self.net.taps(x), target_taps).mean()

@@ -828,3 +828,48 @@ def lpips_tap_bwd(a, b, w, saved, gout):
     L.check(L.lib().pti_lpips_tap_bwd(_ptr(a), _ptr(b), _ptr(w), _ptr(saved), _ptr(gout), _ptr(ga), n, c, h * ww, _stream()),
             "pti_lpips_tap_bwd")
     return ga
+
+
+# ---- trunk of the perceptual network (csrc/squeeze.hip) -----------------------------------------------------------------
+def relu_f16_(x):
+    _chk(x, F16, "x")
+    L.check(L.lib().pti_relu_f16(_ptr(x), x.numel(), _stream()), "pti_relu_f16")
+    return x
+
+
+def relu_bwd_(g, y):
+    """g (bf16) = y > 0 ? g : 0 in place; y: the fp16 ReLU output of the same shape."""
+    _chk(g, BF16, "g")
+    _chk(y, F16, "y")
+    if g.shape != y.shape:
+        raise ValueError("relu_bwd_: shapes")
+    L.check(L.lib().pti_relu_bwd(_ptr(g), _ptr(y), g.numel(), _stream()), "pti_relu_bwd")
+    return g
+
+
+def maxpool3s2_fwd(x):
+    """MaxPool2d(3, 2, ceil_mode=True) on NHWC fp16."""
+    _chk(x, F16, "x", 4)
+    n, h, w, c = x.shape
+    y = torch.empty(n, L.lib().pti_maxpool3s2_out(h), L.lib().pti_maxpool3s2_out(w), c, dtype=F16, device=x.device)
+    L.check(L.lib().pti_maxpool3s2_fwd(_ptr(x), _ptr(y), n, h, w, c, _stream()), "pti_maxpool3s2_fwd")
+    return y
+
+
+def maxpool3s2_bwd(gy, x, y, gx=None):
+    """-> gx (bf16, x's shape): gradient of maxpool3s2_fwd; accumulated into ``gx`` when given."""
+    _chk(gy, BF16, "gy", 4)
+    _chk(x, F16, "x", 4)
+    _chk(y, F16, "y", 4)
+    if gy.shape != y.shape:
+        raise ValueError("maxpool3s2_bwd: shapes")
+    n, h, w, c = x.shape
+    acc = gx is not None
+    if acc:
+        _chk(gx, BF16, "gx", 4)
+        if gx.shape != x.shape:
+            raise ValueError("maxpool3s2_bwd: gx shape")
+    else:
+        gx = torch.empty(x.shape, dtype=BF16, device=x.device)
+    L.check(L.lib().pti_maxpool3s2_bwd(_ptr(gy), _ptr(x), _ptr(y), _ptr(gx), n, h, w, c, int(acc), _stream()), "pti_maxpool3s2_bwd")
+    return gx

@@ -1,0 +1,133 @@
+"""Native trunk of the perceptual (LPIPS / SqueezeNet-1.1) feature network -- SURVEY 8f N3 ("HIP convs reused from K1").
+
+Reference: ``vae_scripts/train_vae.py:299,395-397`` -> ``monai.losses.PerceptualLoss(network_type="squeeze")`` ->
+``lpips.LPIPS(net="squeeze")`` -> ``torchvision.models.squeezenet1_1().features``.  ``models/perceptual.py`` holds the
+parameters (both packages' key names) and the torch formulation; this module runs everything AFTER the first
+convolution on the HIP library:
+
+  * a Fire module = squeeze 1x1 + ReLU, then expand1x1 and expand3x3 + ReLU, concatenated.  Here: ONE 1x1
+    ``pti_conv2d_mfma`` (squeeze channels zero-padded to a multiple of 32) and ONE 3x3 ``pti_conv2d_mfma`` whose first
+    half of output channels carries the 1x1 expand weights at the centre tap -- the concatenation is the output layout;
+  * ReLU / ReLU-backward / MaxPool(3, 2, ceil) forward + backward: ``csrc/squeeze.hip``;
+  * activations NHWC fp16 (forward MFMA operands fp16, as the VAE's forward), gradients NHWC bf16 through the same
+    data-gradient kernels as the VAE's backward (transposed / flipped weight packs).  The network is frozen: no weight
+    gradients, weights packed once.
+
+The first layer (3 -> 64, stride 2, no padding; 3 input channels are outside the MFMA kernels' shapes) stays a torch
+convolution; its ReLU output is tap 0 and the trunk's input.  Parity vs the reference: UNPINNED like the rest of the
+term (no weights available); pinned to the torch formulation of the same network by tests/test_gpu_perceptual.py."""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+F16, BF16 = torch.float16, torch.bfloat16
+
+# squeezenet1_1.features indices after the first conv + ReLU (0, 1): pools at 2, 5, 8; Fire modules elsewhere.
+# taps (lpips slices): after 1 (tap 0 = trunk input), 4, 7, 9, 10, 11, 12.
+_PLAN = (("pool",), ("fire", 3, False), ("fire", 4, True), ("pool",), ("fire", 6, False), ("fire", 7, True), ("pool",),
+         ("fire", 9, True), ("fire", 10, True), ("fire", 11, True), ("fire", 12, True))
+
+
+class _Fire:
+    def __init__(self, f):
+        dev = f.squeeze.weight.device
+        cin, s = f.squeeze.in_channels, f.squeeze.out_channels
+        e1, e3 = f.expand1x1.out_channels, f.expand3x3.out_channels
+        sp = (s + 31) // 32 * 32
+        self.cin, self.sp, self.cout = cin, sp, e1 + e3
+        wsq = torch.zeros(sp, cin, 1, 1, device=dev)
+        wsq[:s] = f.squeeze.weight.detach().float()
+        self.bsq = torch.zeros(sp, device=dev)
+        self.bsq[:s] = f.squeeze.bias.detach().float()
+        wex = torch.zeros(e1 + e3, sp, 3, 3, device=dev)
+        wex[:e1, :s, 1, 1] = f.expand1x1.weight.detach().float()[:, :, 0, 0]
+        wex[e1:, :s] = f.expand3x3.weight.detach().float()
+        self.bex = torch.cat([f.expand1x1.bias.detach().float(), f.expand3x3.bias.detach().float()]).contiguous()
+        self.wsq = ops.pack_conv_weight(wsq.contiguous(), 1, f16=True)
+        self.wex = ops.pack_conv_weight(wex.contiguous(), 3, f16=True)
+        self.wsq_t = ops.pack_conv_weight(wsq.contiguous(), 1, flip=True)
+        self.wex_t = ops.pack_conv_weight(wex.contiguous(), 3, flip=True)
+
+    def fwd(self, x):
+        n, h, w, _ = x.shape
+        s = torch.empty(n, h, w, self.sp, dtype=F16, device=x.device)
+        ops.conv_mfma(x, self.wsq, self.bsq, s, cout=self.sp, ksize=1)
+        ops.relu_f16_(s)
+        e = torch.empty(n, h, w, self.cout, dtype=F16, device=x.device)
+        ops.conv_mfma(s, self.wex, self.bex, e, cout=self.cout, ksize=3)
+        ops.relu_f16_(e)
+        return s, e
+
+    def bwd(self, ge, s, e):
+        """ge: gradient w.r.t. the module's (post-ReLU) output, consumed in place -> gradient w.r.t. its input."""
+        n, h, w, _ = e.shape
+        ops.relu_bwd_(ge, e)
+        gs = torch.empty(n, h, w, self.sp, dtype=BF16, device=e.device)
+        ops.conv_mfma(ge, self.wex_t, None, gs, cout=self.sp, ksize=3)
+        ops.relu_bwd_(gs, s)
+        gx = torch.empty(n, h, w, self.cin, dtype=BF16, device=e.device)
+        ops.conv_mfma(gs, self.wsq_t, None, gx, cout=self.cin, ksize=1)
+        return gx
+
+
+class SqueezeTrunk:
+    """Built from a ``models.perceptual.SqueezeLPIPS`` on the HIP device (weights are read once: the network is frozen)."""
+
+    def __init__(self, net):
+        self.fires = {i: _Fire(net.features[i]) for st in _PLAN if st[0] == "fire" for i in (st[1],)}
+        self.c0 = net.features[0].out_channels
+
+    @staticmethod
+    def to_nhwc_f16(t0):
+        """tap 0 as torch leaves it (NCHW fp32) -> NHWC fp16."""
+        return t0.to(F16).contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+
+    @staticmethod
+    def to_nchw_f32(x):
+        """NHWC 16-bit -> NCHW fp32 contiguous (the layout of the comparison kernels)."""
+        return x.permute(0, 3, 1, 2).float().contiguous()
+
+    @staticmethod
+    def to_nhwc_bf16(g):
+        """NCHW fp32 gradient -> NHWC bf16."""
+        return g.to(BF16).contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+
+    def forward(self, x0, save: bool):
+        """x0: NHWC fp16 [N, H, W, 64] (ReLU output of the first convolution) -> (taps 1..6 as NHWC fp16, saved)."""
+        if x0.dtype != F16 or x0.dim() != 4 or x0.shape[3] != self.c0 or not x0.is_contiguous():
+            raise ValueError("SqueezeTrunk.forward: expected a contiguous NHWC fp16 tensor with %d channels" % self.c0)
+        taps, saved, x = [], [], x0
+        for st in _PLAN:
+            if st[0] == "pool":
+                y = ops.maxpool3s2_fwd(x)
+                if save:
+                    saved.append(("pool", x, y))
+                x = y
+            else:
+                s, e = self.fires[st[1]].fwd(x)
+                if save:
+                    saved.append(("fire", st[1], st[2], s, e))
+                if st[2]:
+                    taps.append(e)
+                x = e
+        return taps, saved
+
+    def backward(self, saved, tap_grads):
+        """tap_grads: NHWC bf16 gradients w.r.t. taps 1..6 (consumed) -> NHWC bf16 gradient w.r.t. x0."""
+        g, k = None, len(tap_grads) - 1
+        for st in reversed(saved):
+            if st[0] == "pool":
+                g = ops.maxpool3s2_bwd(g, st[1], st[2])
+            else:
+                _, idx, is_tap, s, e = st
+                if is_tap:
+                    ge = tap_grads[k]
+                    k -= 1
+                    if g is not None:
+                        ge.add_(g)
+                else:
+                    ge = g
+                g = self.fires[idx].bwd(ge, s, e)
+        return g

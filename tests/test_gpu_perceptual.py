@@ -96,6 +96,7 @@ def test_whole_term_fused_tail_equals_torch_tail(dev):
     from pti_ldm_vae_amd.models import PerceptualLoss
     torch.manual_seed(3)
     pl = PerceptualLoss(allow_random_init=True).to(dev)
+    pl.net.native_trunk = False          # torch feature network + HIP tail
     ref = copy.deepcopy(pl)
     ref.net.fused_tail = False
     g = torch.Generator().manual_seed(4)
@@ -109,3 +110,107 @@ def test_whole_term_fused_tail_equals_torch_tail(dev):
     print(f"[lpips term] fused {l1.item():.6e} vs torch {l2.item():.6e}; grad relL2 {rel:.2e}")
     assert l1.item() == pytest.approx(l2.item(), rel=1e-5)
     assert rel <= 1e-4
+
+
+# ---- the trunk of the feature network on the HIP library (perceptual_engine.SqueezeTrunk) --------------------------------
+def _rel(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("shape", [(2, 127, 127, 64), (1, 63, 63, 128), (3, 31, 31, 256), (2, 8, 10, 16), (1, 3, 3, 8), (1, 2, 5, 8)])
+def test_maxpool_ceil_forward_backward_vs_torch(dev, shape):
+    """MaxPool2d(3, 2, ceil_mode=True) on NHWC fp16 (odd sizes: every window complete; even sizes: clipped windows):
+    forward bit-equal to torch, backward (gather) equal to torch's where the maximum is unique -- the inputs are
+    continuous random values, so ties have probability ~0 -- and accumulation into an existing gradient."""
+    import torch.nn.functional as F
+    from pti_ldm_vae_amd import ops
+    g = torch.Generator().manual_seed(sum(shape))
+    # fp16-exact values that are pairwise distinct inside every 3x3 window (random fp16 values tie in ~1 % of windows,
+    # where torch picks the first maximum and the gather shares the gradient)
+    n_, h_, w_, c_ = shape
+    ii = (torch.arange(h_).view(1, -1, 1, 1) * 37 + torch.arange(w_).view(1, 1, -1, 1) * 101
+          + torch.arange(c_).view(1, 1, 1, -1) * 7 + torch.arange(n_).view(-1, 1, 1, 1) * 13) % 1024
+    x = ((ii.float() - 512.0) / 64.0).half().to(dev)
+    y = ops.maxpool3s2_fwd(x)
+    xt = x.permute(0, 3, 1, 2).float().requires_grad_(True)
+    yt = F.max_pool2d(xt, 3, 2, ceil_mode=True)
+    assert tuple(y.shape) == (shape[0], yt.shape[2], yt.shape[3], shape[3])
+    assert torch.equal(y.permute(0, 3, 1, 2).float(), yt.detach())
+    gy = torch.randn(*y.shape, generator=g).to(dev).bfloat16()
+    gxt, = torch.autograd.grad(yt, xt, gy.permute(0, 3, 1, 2).float())
+    gx = ops.maxpool3s2_bwd(gy, x, y)
+    # up to 4 bf16 gradients are summed in fp32 and rounded once; torch sums fp32 values exactly
+    assert torch.allclose(gx.permute(0, 3, 1, 2).float(), gxt, rtol=1e-2, atol=1e-3)
+    base = torch.randn(*shape, generator=g).to(dev).bfloat16()
+    acc = ops.maxpool3s2_bwd(gy, x, y, gx=base.clone())
+    assert torch.allclose(acc.float(), base.float() + gxt.permute(0, 2, 3, 1), rtol=2e-2, atol=2e-2)
+
+
+def test_relu_passes(dev):
+    from pti_ldm_vae_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(3, 5, 7, 16, generator=g).half().to(dev)
+    y = ops.relu_f16_(x.clone())
+    assert torch.equal(y, x.clamp_min(0))
+    gr = torch.randn(3, 5, 7, 16, generator=g).to(dev).bfloat16()
+    out = ops.relu_bwd_(gr.clone(), y)
+    assert torch.equal(out, torch.where(y > 0, gr, torch.zeros_like(gr)))
+    with pytest.raises((ValueError, TypeError, RuntimeError)):
+        ops.relu_f16_(torch.zeros(7, device=dev).half())          # not a multiple of 8
+
+
+@pytest.mark.parametrize("idx,hw", [(3, 63), (7, 31), (10, 15), (12, 15)])
+def test_fire_module_forward_and_input_gradient_vs_torch(dev, idx, hw):
+    """One Fire module on the HIP library (two MFMA convolutions, merged expands) vs the torch module in fp32: fp16 forward
+    operands -> rel-L2 3e-3 forward (measured 4e-4); bf16 gradients (the incoming one is rounded to bf16 too) and ReLU
+    masks taken from the fp16 squeeze output (a value within rounding of 0 flips its mask) -> gradient rel-L2 3e-2
+    (measured 1.1-1.8e-2), cosine >= 0.9995."""
+    from pti_ldm_vae_amd.models.perceptual import SqueezeLPIPS
+    from pti_ldm_vae_amd.perceptual_engine import _Fire
+    torch.manual_seed(idx)
+    net = SqueezeLPIPS().to(dev)
+    f = net.features[idx]
+    cin = f.squeeze.in_channels
+    x = torch.randn(2, cin, hw, hw, device=dev).relu()
+    xt = x.clone().requires_grad_(True)
+    yt = f(xt)
+    gy = torch.randn_like(yt) * (yt > 0)
+    gxt, = torch.autograd.grad(yt, xt, gy)
+    fire = _Fire(f)
+    xn = x.half().contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+    s, e = fire.fwd(xn)
+    r_f = _rel(e.permute(0, 3, 1, 2).float(), yt.detach())
+    gx = fire.bwd(gy.bfloat16().contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).clone(), s, e)
+    r_g = _rel(gx.permute(0, 3, 1, 2).float(), gxt)
+    print(f"[fire {idx} @{hw}] forward relL2 {r_f:.2e}, input-gradient relL2 {r_g:.2e}")
+    cos = torch.nn.functional.cosine_similarity(gx.permute(0, 3, 1, 2).flatten().double(), gxt.flatten().double(), dim=0).item()
+    assert r_f <= 3e-3 and r_g <= 3e-2 and cos >= 0.9995
+
+
+def test_whole_term_native_trunk_vs_torch_network(dev):
+    """The whole perceptual term with the HIP trunk + tail vs the torch network + torch tail at 256x256: value within
+    5e-3 relative, gradient w.r.t. the reconstruction cosine >= 0.999 (16-bit feature maps vs fp32)."""
+    import copy
+    from pti_ldm_vae_amd.models import PerceptualLoss
+    torch.manual_seed(3)
+    pl = PerceptualLoss(allow_random_init=True).to(dev)
+    ref = copy.deepcopy(pl)
+    ref.net.native_trunk = False
+    ref.net.fused_tail = False
+    g = torch.Generator().manual_seed(4)
+    y = torch.rand(3, 1, 256, 256, generator=g).to(dev)
+    x = (y + 0.1 * torch.randn(3, 1, 256, 256, generator=g).to(dev)).requires_grad_(True)
+    assert pl.net.use_native(x)
+    l1 = pl(x, y)
+    g1, = torch.autograd.grad(l1, x)
+    l2 = ref(x, y)
+    g2, = torch.autograd.grad(l2, x)
+    cos = torch.nn.functional.cosine_similarity(g1.flatten().double(), g2.flatten().double(), dim=0).item()
+    print(f"[lpips term, native trunk] {l1.item():.6e} vs torch {l2.item():.6e}; grad cosine {cos:.6f}, relL2 {_rel(g1, g2):.2e}")
+    assert l1.item() == pytest.approx(l2.item(), rel=5e-3)
+    assert cos >= 0.999 and torch.isfinite(g1).all()
+    # split API used by the trainer: target taps first, then the comparison
+    l3 = pl.from_taps(x, pl.target_taps(y))
+    assert l3.item() == l1.item()
+    # identical images: exactly zero
+    assert pl(y, y).item() == 0.0
