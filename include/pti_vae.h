@@ -367,13 +367,33 @@ int pti_lpips_tap_bwd(const float* a, const float* b, const float* w, const floa
  *   pti_relu_bwd:        g = y > 0 ? g : 0 in place (y = the ReLU OUTPUT).
  *   pti_maxpool3s2_out:  pooled size of one spatial dimension.
  *   pti_maxpool3s2_fwd:  y [n][ho][wo][c] = max over the (clipped) 3x3 windows of x [n][h][w][c].
- *   pti_maxpool3s2_bwd:  gx (+)= gather of gy over the windows whose maximum the element is (no atomics).             */
+ *   pti_maxpool3s2_bwd:  gx (+)= gather of gy over the windows whose maximum the element is (no atomics).
+ *   pti_nchw_f32_to_nhwc_f16 / pti_nhwc_bf16_add_to_nchw_f32: the trunk's boundary with torch's layout (tap 0):
+ *                        y[n][p][c] = (fp16) x[n][c][p];   y[n][c][p] += (float) g[n][p][c];   c a multiple of 64.
+ *   pti_lpips_tap_nhwc_*: pti_lpips_tap_* on the trunk's layout -- a, b fp16 [n][hw][c], ga bf16 [n][hw][c]; same
+ *                        `saved` / `partials` contract with pti_lpips_tap_nhwc_blocks(c, hw); c = 8 * L * k with
+ *                        L in {8, 16, 32, 64}, k <= 4 (0 blocks = unsupported channel count).
+ *   pti_squeeze_conv1_*: the first layer (3 -> 64, 3x3, stride 2, no padding, + ReLU) for a ONE-channel image whose three
+ *                        copies the reference scales per channel (ensure_three_channels + lpips ScalingLayer), folded
+ *                        into a 1 -> 64 convolution: w10 fp32 [10][64] = {W'[tap][co] = sum_c W[co][c][tap] / scale_c,
+ *                        b'[co] = b[co] - sum_c shift_c / scale_c * sum_tap W[co][c][tap]}.  x fp32 [n][h][w];
+ *                        fwd: y fp16 [n][(h-3)/2+1][(w-3)/2+1][64] = tap 0;  bwd: dx fp32 [n][h][w] from the bf16
+ *                        gradient g w.r.t. tap 0 (ReLU mask taken from t0 = y).                                          */
 int pti_relu_f16(void* x, int64_t count, pti_stream_t s);
 int pti_relu_bwd(void* g, const void* y, int64_t count, pti_stream_t s);
 int pti_maxpool3s2_out(int h);
 int pti_maxpool3s2_fwd(const void* x, void* y, int n, int h, int w, int c, pti_stream_t s);
 int pti_maxpool3s2_bwd(const void* gy, const void* x, const void* y, void* gx, int n, int h, int w, int c, int accumulate,
                        pti_stream_t s);
+int pti_squeeze_conv1_fwd(const float* x, const float* w10, void* y, int n, int h, int w, pti_stream_t s);
+int pti_squeeze_conv1_bwd(const void* g, const void* t0, const float* w10, float* dx, int n, int h, int w, pti_stream_t s);
+int pti_nchw_f32_to_nhwc_f16(const float* x, void* y, int n, int c, int hw, pti_stream_t s);
+int pti_nhwc_bf16_add_to_nchw_f32(const void* g, float* y, int n, int c, int hw, pti_stream_t s);
+int pti_lpips_tap_nhwc_blocks(int c, int hw);
+int pti_lpips_tap_nhwc_fwd(const void* a, const void* b, const float* w, float* saved, float* partials, int n, int c,
+                           int hw, pti_stream_t s);
+int pti_lpips_tap_nhwc_bwd(const void* a, const void* b, const float* w, const float* saved, const float* gout, void* ga,
+                           int n, int c, int hw, pti_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -104,6 +104,13 @@ SIGNATURES = {
     "pti_maxpool3s2_out": (_I, [_I]),
     "pti_maxpool3s2_fwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "pti_maxpool3s2_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "pti_squeeze_conv1_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "pti_squeeze_conv1_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "pti_nchw_f32_to_nhwc_f16": (_I, [_P, _P, _I, _I, _I, _P]),
+    "pti_nhwc_bf16_add_to_nchw_f32": (_I, [_P, _P, _I, _I, _I, _P]),
+    "pti_lpips_tap_nhwc_blocks": (_I, [_I, _I]),
+    "pti_lpips_tap_nhwc_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "pti_lpips_tap_nhwc_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "pti_adam_step": (_I, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I, _F, _P]),
     "pti_preprocess_batch": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "pti_cast_nchw_f32_to_nhwc_bf16": (_I, [_P, _P, _I, _I, _I, _P]),

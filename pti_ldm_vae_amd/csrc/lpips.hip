@@ -122,6 +122,138 @@ __global__ __launch_bounds__(256) void lpips_tap_bwd_kernel(const float* __restr
   }
 }
 
+// ---- the same comparison on NHWC 16-bit maps (the HIP trunk's layout: a fp16 [n][hw][c], b fp16, gradient bf16) ----
+// LP lanes share a pixel (LP = the largest power of two <= 64 dividing c/8), lane l holding the 8-channel pieces
+// l, l + LP, ... (<= LP_MAXP of them) in registers, so each map is read ONCE forward; channel sums are xor-butterflies
+// over the LP lanes (every lane ends with the total, fixed order), the pixels of a workgroup are folded by thread 0.
+constexpr int LP_MAXP = 4;
+typedef _Float16 lp_f16x8 __attribute__((ext_vector_type(8)));
+
+// Sum of the squares of one 8-channel fp16 piece.  NOT inlined on purpose: both maps go through the very same
+// instructions, so identical maps get bit-identical norms (inlined, the compiler picked different fp16 -> fp32 / fma
+// forms for the two maps and identical images compared as 1e-16 instead of exactly 0).
+__device__ __attribute__((noinline)) float lp_sumsq8(u32x4 piece) {
+  const lp_f16x8 v = __builtin_bit_cast(lp_f16x8, piece);
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float x = (float)v[e];
+    s += x * x;
+  }
+  return s;
+}
+
+template <int LP>
+__device__ __forceinline__ float lp_group_sum(float v) {
+#pragma unroll
+  for (int o = LP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int LP>
+__global__ __launch_bounds__(256) void lpips_tap_nhwc_fwd_kernel(const u32x4* __restrict__ a, const u32x4* __restrict__ b,
+                                                                 const float* __restrict__ w, float* __restrict__ saved,
+                                                                 float* __restrict__ part, int NC, int HW) {
+  constexpr int PIX = 256 / LP;
+  __shared__ float red[PIX];
+  const int tid = threadIdx.x, l = tid % LP, pl = tid / LP, n = blockIdx.y;
+  const int p = blockIdx.x * PIX + pl;
+  const bool ok = p < HW;
+  const int ppl = NC / LP;
+  float xa[LP_MAXP][8], xb[LP_MAXP][8];
+  float sa = 0.f, sb = 0.f;
+#pragma unroll
+  for (int j = 0; j < LP_MAXP; ++j) {
+    if (j < ppl && ok) {
+      const size_t o = ((size_t)n * HW + p) * NC + l + j * LP;
+      const u32x4 ra_ = a[o], rb_ = b[o];
+      const lp_f16x8 va = __builtin_bit_cast(lp_f16x8, ra_), vb = __builtin_bit_cast(lp_f16x8, rb_);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        xa[j][e] = (float)va[e];
+        xb[j][e] = (float)vb[e];
+      }
+      sa += lp_sumsq8(ra_);
+      sb += lp_sumsq8(rb_);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xa[j][e] = xb[j][e] = 0.f;
+    }
+  }
+  const float ra = sqrtf(lp_group_sum<LP>(sa)), rb = sqrtf(lp_group_sum<LP>(sb));
+  const float ia = 1.f / (ra + LP_EPS), ib = 1.f / (rb + LP_EPS), dab = ia - ib;
+  float sd = 0.f, sq = 0.f;
+#pragma unroll
+  for (int j = 0; j < LP_MAXP; ++j) {
+    if (j < ppl) {
+      const float* wp = w + (l + j * LP) * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = lp_diff(xa[j][e], ia, xb[j][e], dab);
+        const float wd = wp[e] * d;
+        sd += wd * d;
+        sq += wd * xa[j][e];
+      }
+    }
+  }
+  sd = lp_group_sum<LP>(sd);
+  sq = lp_group_sum<LP>(sq);
+  if (l == 0) {
+    if (ok) {
+      float* sv = saved + (size_t)n * 3 * HW + p;
+      sv[0] = ra;
+      sv[HW] = rb;
+      sv[2 * (size_t)HW] = sq;
+    }
+    red[pl] = ok ? sd : 0.f;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < PIX; ++i) v += red[i];
+    part[(size_t)n * gridDim.x + blockIdx.x] = v;
+  }
+}
+
+template <int LP>
+__global__ __launch_bounds__(256) void lpips_tap_nhwc_bwd_kernel(const u32x4* __restrict__ a, const u32x4* __restrict__ b,
+                                                                 const float* __restrict__ w, const float* __restrict__ saved,
+                                                                 const float* __restrict__ gout, u32x4* __restrict__ ga,
+                                                                 int NC, int HW, float inv_hw) {
+  constexpr int PIX = 256 / LP;
+  const int tid = threadIdx.x, l = tid % LP, pl = tid / LP, n = blockIdx.y;
+  const int p = blockIdx.x * PIX + pl;
+  if (p >= HW) return;
+  const int ppl = NC / LP;
+  const float* sv = saved + (size_t)n * 3 * HW + p;
+  const float ra = sv[0], rb = sv[HW], q = sv[2 * (size_t)HW];
+  const float ia = 1.f / (ra + LP_EPS), ib = 1.f / (rb + LP_EPS), dab = ia - ib;
+  const float k = 2.f * gout[n] * inv_hw * ia;
+  const float m = ra > 0.f ? q * ia / ra : 0.f;
+  for (int j = 0; j < ppl; ++j) {
+    const size_t o = ((size_t)n * HW + p) * NC + l + j * LP;
+    const lp_f16x8 va = __builtin_bit_cast(lp_f16x8, a[o]), vb = __builtin_bit_cast(lp_f16x8, b[o]);
+    const float* wp = w + (l + j * LP) * 8;
+    float g[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x = (float)va[e];
+      g[e] = k * (wp[e] * lp_diff(x, ia, (float)vb[e], dab) - m * x);
+    }
+    ga[o] = pack8(g);
+  }
+}
+
+// lanes per pixel of the NHWC kernels (0: unsupported channel count)
+int lp_lanes(int c) {
+  if (c <= 0 || c % 8) return 0;
+  const int nc = c / 8;
+  for (int lp = 64; lp >= 8; lp /= 2)
+    if (nc % lp == 0 && nc / lp <= LP_MAXP) return lp;
+  return 0;
+}
+
 // channel slices per pixel: enough that a thread walks <= 64 channels (the small late taps would otherwise be a few
 // dozen workgroups of 512-step serial loops), and S | C
 int lp_slices(int c) {
@@ -172,5 +304,50 @@ extern "C" int pti_lpips_tap_bwd(const float* a, const float* b, const float* w,
     default: PTI_LAUNCH(lpips_tap_bwd_kernel<8>, grid, dim3(256), 0, st, a, b, w, saved, gout, ga, c, hw, inv_hw); break;
   }
   PTI_CHECK_LAUNCH("lpips_tap_bwd");
+  return PTI_OK;
+}
+
+extern "C" int pti_lpips_tap_nhwc_blocks(int c, int hw) {
+  const int lp = lp_lanes(c);
+  if (!lp || hw <= 0) return 0;
+  return (hw + 256 / lp - 1) / (256 / lp);
+}
+
+extern "C" int pti_lpips_tap_nhwc_fwd(const void* a, const void* b, const float* w, float* saved, float* partials, int n,
+                                      int c, int hw, pti_stream_t s) {
+  if (!a || !b || !w || !saved || !partials) PTI_FAIL(PTI_EINVAL, "lpips_tap_nhwc_fwd: null pointer");
+  const int lp = lp_lanes(c);
+  if (!lp) PTI_FAIL(PTI_EUNSUPPORTED, "lpips_tap_nhwc_fwd: c=%d (need 8 * L * k, L in {8,16,32,64}, k <= 4)", c);
+  if (n <= 0 || hw <= 0 || n > 65535) PTI_FAIL(PTI_EINVAL, "lpips_tap_nhwc_fwd: bad dims n=%d hw=%d", n, hw);
+  const dim3 grid((hw + 256 / lp - 1) / (256 / lp), n);
+  hipStream_t st = (hipStream_t)s;
+  const u32x4 *pa = (const u32x4*)a, *pb = (const u32x4*)b;
+  switch (lp) {
+    case 8: PTI_LAUNCH(lpips_tap_nhwc_fwd_kernel<8>, grid, dim3(256), 0, st, pa, pb, w, saved, partials, c / 8, hw); break;
+    case 16: PTI_LAUNCH(lpips_tap_nhwc_fwd_kernel<16>, grid, dim3(256), 0, st, pa, pb, w, saved, partials, c / 8, hw); break;
+    case 32: PTI_LAUNCH(lpips_tap_nhwc_fwd_kernel<32>, grid, dim3(256), 0, st, pa, pb, w, saved, partials, c / 8, hw); break;
+    default: PTI_LAUNCH(lpips_tap_nhwc_fwd_kernel<64>, grid, dim3(256), 0, st, pa, pb, w, saved, partials, c / 8, hw); break;
+  }
+  PTI_CHECK_LAUNCH("lpips_tap_nhwc_fwd");
+  return PTI_OK;
+}
+
+extern "C" int pti_lpips_tap_nhwc_bwd(const void* a, const void* b, const float* w, const float* saved, const float* gout,
+                                      void* ga, int n, int c, int hw, pti_stream_t s) {
+  if (!a || !b || !w || !saved || !gout || !ga) PTI_FAIL(PTI_EINVAL, "lpips_tap_nhwc_bwd: null pointer");
+  const int lp = lp_lanes(c);
+  if (!lp) PTI_FAIL(PTI_EUNSUPPORTED, "lpips_tap_nhwc_bwd: c=%d", c);
+  if (n <= 0 || hw <= 0 || n > 65535) PTI_FAIL(PTI_EINVAL, "lpips_tap_nhwc_bwd: bad dims n=%d hw=%d", n, hw);
+  const dim3 grid((hw + 256 / lp - 1) / (256 / lp), n);
+  hipStream_t st = (hipStream_t)s;
+  const u32x4 *pa = (const u32x4*)a, *pb = (const u32x4*)b;
+  const float inv_hw = 1.0f / (float)hw;
+  switch (lp) {
+    case 8: PTI_LAUNCH(lpips_tap_nhwc_bwd_kernel<8>, grid, dim3(256), 0, st, pa, pb, w, saved, gout, (u32x4*)ga, c / 8, hw, inv_hw); break;
+    case 16: PTI_LAUNCH(lpips_tap_nhwc_bwd_kernel<16>, grid, dim3(256), 0, st, pa, pb, w, saved, gout, (u32x4*)ga, c / 8, hw, inv_hw); break;
+    case 32: PTI_LAUNCH(lpips_tap_nhwc_bwd_kernel<32>, grid, dim3(256), 0, st, pa, pb, w, saved, gout, (u32x4*)ga, c / 8, hw, inv_hw); break;
+    default: PTI_LAUNCH(lpips_tap_nhwc_bwd_kernel<64>, grid, dim3(256), 0, st, pa, pb, w, saved, gout, (u32x4*)ga, c / 8, hw, inv_hw); break;
+  }
+  PTI_CHECK_LAUNCH("lpips_tap_nhwc_bwd");
   return PTI_OK;
 }

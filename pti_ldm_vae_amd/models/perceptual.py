@@ -94,32 +94,67 @@ class _LpipsTapFn(torch.autograd.Function):
 
 class _TrunkCompareFn(torch.autograd.Function):
     """LPIPS value [N] from tap 0 of the reconstruction (NCHW fp32, output of the torch first layer) and the target's
-    seven taps, with the rest of the feature network on the HIP trunk (``perceptual_engine.SqueezeTrunk``) and the
-    comparison on the tail kernels; gradient to tap 0 only."""
+    seven taps (``SqueezeLPIPS.native_target_taps``: tap 0 NCHW fp32, taps 1..6 NHWC fp16), with the rest of the feature
+    network on the HIP trunk (``perceptual_engine.SqueezeTrunk``) and the comparison on the tail kernels in each map's own
+    layout; gradient to tap 0 only."""
 
     @staticmethod
     def forward(ctx, t0, trunk, target, lin_ws):
         from .. import ops
         t0 = t0.contiguous()
-        taps, saved = trunk.forward(trunk.to_nhwc_f16(t0), save=True)
-        feats = [t0] + [trunk.to_nchw_f32(t) for t in taps]
-        total, tails = None, []
-        for a, b, w in zip(feats, target, lin_ws):
-            val, sv = ops.lpips_tap_fwd(a, b, w)
+        taps, saved = trunk.forward(ops.nchw_f32_to_nhwc_f16(t0), save=True)
+        total, sv0 = ops.lpips_tap_fwd(t0, target[0], lin_ws[0])
+        tails = [sv0]
+        for a, b, w in zip(taps, target[1:], lin_ws[1:]):
+            val, sv = ops.lpips_tap_nhwc_fwd(a, b, w)
             tails.append(sv)
-            total = val if total is None else total + val
-        ctx.trunk, ctx.saved, ctx.feats, ctx.target, ctx.lin_ws, ctx.tails = trunk, saved, feats, target, lin_ws, tails
+            total = total + val
+        ctx.trunk, ctx.saved, ctx.feats, ctx.target, ctx.lin_ws, ctx.tails = trunk, saved, [t0] + taps, target, lin_ws, tails
         return total
 
     @staticmethod
     def backward(ctx, g):
         from .. import ops
         g = g.contiguous().float()
-        gas = [ops.lpips_tap_bwd(a, b, w, sv, g) for a, b, w, sv in zip(ctx.feats, ctx.target, ctx.lin_ws, ctx.tails)]
-        trunk = ctx.trunk
-        g0 = trunk.backward(ctx.saved, [trunk.to_nhwc_bf16(x) for x in gas[1:]])
+        f, t, w, sv = ctx.feats, ctx.target, ctx.lin_ws, ctx.tails
+        g_t0 = ops.lpips_tap_bwd(f[0], t[0], w[0], sv[0], g)
+        tap_grads = [ops.lpips_tap_nhwc_bwd(f[k], t[k], w[k], sv[k], g) for k in range(1, len(f))]
+        g0 = ctx.trunk.backward(ctx.saved, tap_grads)
         ctx.saved = ctx.feats = ctx.tails = None
-        return gas[0] + trunk.to_nchw_f32(g0), None, None, None
+        return ops.nhwc_bf16_add_to_nchw_f32_(g0.contiguous(), g_t0), None, None, None
+
+
+class _OneChannelCompareFn(torch.autograd.Function):
+    """LPIPS value [N] of a ONE-channel reconstruction [N,1,H,W] against the target's seven taps (all NHWC fp16, from
+    ``SqueezeLPIPS.native_target_taps`` on a one-channel target): the whole feature network on the HIP library -- first
+    layer folded to one input channel (``perceptual_engine.fold_first_layer``), trunk, comparison -- and the gradient
+    w.r.t. the one-channel image (the sum over the three repeated channels is part of the fold)."""
+
+    @staticmethod
+    def forward(ctx, x1, trunk, target, lin_ws):
+        from .. import ops
+        x1 = x1.contiguous()
+        t0 = ops.squeeze_conv1_fwd(x1, trunk.w10)
+        taps, saved = trunk.forward(t0, save=True)
+        feats, total, tails = [t0] + taps, None, []
+        for a, b, w in zip(feats, target, lin_ws):
+            val, sv = ops.lpips_tap_nhwc_fwd(a, b, w)
+            tails.append(sv)
+            total = val if total is None else total + val
+        ctx.trunk, ctx.saved, ctx.feats, ctx.target, ctx.lin_ws, ctx.tails = trunk, saved, feats, target, lin_ws, tails
+        ctx.hw = (x1.shape[-2], x1.shape[-1])
+        return total
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import ops
+        g = g.contiguous().float()
+        f, t, w, sv = ctx.feats, ctx.target, ctx.lin_ws, ctx.tails
+        tap_grads = [ops.lpips_tap_nhwc_bwd(f[k], t[k], w[k], sv[k], g) for k in range(len(f))]
+        g0 = tap_grads[0].add_(ctx.trunk.backward(ctx.saved, tap_grads[1:]))
+        dx = ops.squeeze_conv1_bwd(g0, f[0], ctx.trunk.w10, *ctx.hw)
+        ctx.saved = ctx.feats = ctx.tails = None
+        return dx, None, None, None
 
 
 def lpips_tap_torch(a, b, lin_weight):
@@ -179,15 +214,29 @@ class SqueezeLPIPS(nn.Module):
 
     @torch.no_grad()
     def native_target_taps(self, x):
-        """The seven taps of the TARGET as NCHW fp32 (what ``native_compare`` consumes), no autograd graph."""
-        tr = self.trunk()
+        """The seven taps of the TARGET as ``native_compare`` consumes them (tap 0 NCHW fp32 as the torch first layer
+        leaves it, taps 1..6 NHWC fp16 from the HIP trunk), no autograd graph."""
+        from .. import ops
         t0 = self.tap0(x).contiguous()
-        taps, _ = tr.forward(tr.to_nhwc_f16(t0), save=False)
-        return [t0] + [tr.to_nchw_f32(t) for t in taps]
+        taps, _ = self.trunk().forward(ops.nchw_f32_to_nhwc_f16(t0), save=False)
+        return [t0] + taps
 
     def native_compare(self, in0, target_taps):
         lin_ws = [getattr(self, f"lin{k}").model[1].weight.view(-1) for k in range(len(self.SLICES))]
         return _TrunkCompareFn.apply(self.tap0(in0), self.trunk(), target_taps, lin_ws).view(-1, 1, 1, 1)
+
+    # one-channel images (what the VAE produces): the first layer too runs on the HIP library, folded to one channel
+    @torch.no_grad()
+    def native_target_taps_1ch(self, x1):
+        from .. import ops
+        tr = self.trunk()
+        t0 = ops.squeeze_conv1_fwd(x1.contiguous(), tr.w10)
+        taps, _ = tr.forward(t0, save=False)
+        return [t0] + taps
+
+    def native_compare_1ch(self, x1, target_taps):
+        lin_ws = [getattr(self, f"lin{k}").model[1].weight.view(-1) for k in range(len(self.SLICES))]
+        return _OneChannelCompareFn.apply(x1, self.trunk(), target_taps, lin_ws).view(-1, 1, 1, 1)
 
     def forward(self, in0, in1):
         if self.use_native(in0):
@@ -248,18 +297,27 @@ class PerceptualLoss(nn.Module):
                                "(or allow_random_init=True for tests / throughput runs).")
         self.pretrained = weights is not None
 
+    def _one_channel_native(self, t: torch.Tensor) -> bool:
+        return t.dim() == 4 and t.shape[1] == 1 and self.net.use_native(t.float()) and min(t.shape[2:]) >= 3
+
     def forward(self, input: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        if self._one_channel_native(input) and self._one_channel_native(target):
+            return self.from_taps(input, self.target_taps(target))
         return self.net(ensure_three_channels(input.float()), ensure_three_channels(target.float())).mean()
 
     @torch.no_grad()
     def target_taps(self, target: torch.Tensor):
         """The target's feature taps alone (no autograd graph): they do not depend on the reconstruction, so the trainer
         computes them on its side stream while the VAE forward runs, and hands them to ``from_taps``."""
+        if self._one_channel_native(target):
+            return self.net.native_target_taps_1ch(target.float())
         x = ensure_three_channels(target.float())
         return self.net.native_target_taps(x) if self.net.use_native(x) else self.net.taps(x)
 
     def from_taps(self, input: torch.Tensor, target_taps) -> torch.Tensor:
         """``forward(input, target)`` with the target's taps precomputed by ``target_taps(target)``."""
+        if self._one_channel_native(input) and target_taps[0].dtype == torch.float16:
+            return self.net.native_compare_1ch(input.float(), target_taps).mean()
         x = ensure_three_channels(input.float())
         if self.net.use_native(x):
             return self.net.native_compare(x, target_taps).mean()

@@ -873,3 +873,88 @@ def maxpool3s2_bwd(gy, x, y, gx=None):
         gx = torch.empty(x.shape, dtype=BF16, device=x.device)
     L.check(L.lib().pti_maxpool3s2_bwd(_ptr(gy), _ptr(x), _ptr(y), _ptr(gx), n, h, w, c, int(acc), _stream()), "pti_maxpool3s2_bwd")
     return gx
+
+
+def nchw_f32_to_nhwc_f16(x):
+    """fp32 [n, c, h, w] -> fp16 [n, h, w, c] (c a multiple of 64)."""
+    _chk(x, F32, "x", 4)
+    n, c, h, w = x.shape
+    y = torch.empty(n, h, w, c, dtype=F16, device=x.device)
+    L.check(L.lib().pti_nchw_f32_to_nhwc_f16(_ptr(x), _ptr(y), n, c, h * w, _stream()), "pti_nchw_f32_to_nhwc_f16")
+    return y
+
+
+def nhwc_bf16_add_to_nchw_f32_(g, y):
+    """y (fp32 [n, c, h, w]) += g (bf16 [n, h, w, c])."""
+    _chk(g, BF16, "g", 4)
+    _chk(y, F32, "y", 4)
+    n, c, h, w = y.shape
+    if tuple(g.shape) != (n, h, w, c):
+        raise ValueError("nhwc_bf16_add_to_nchw_f32_: shapes")
+    L.check(L.lib().pti_nhwc_bf16_add_to_nchw_f32(_ptr(g), _ptr(y), n, c, h * w, _stream()), "pti_nhwc_bf16_add_to_nchw_f32")
+    return y
+
+
+def lpips_tap_nhwc_supported(c):
+    return L.lib().pti_lpips_tap_nhwc_blocks(int(c), 1) > 0
+
+
+def lpips_tap_nhwc_fwd(a, b, w):
+    """lpips_tap_fwd on NHWC fp16 maps [n, h, w_, c] -> (value [n], saved [n, 3, h*w_])."""
+    _chk(a, F16, "a", 4)
+    _chk(b, F16, "b", 4)
+    _chk(w, F32, "w", 1)
+    if a.shape != b.shape or w.numel() != a.shape[3]:
+        raise ValueError("lpips_tap_nhwc_fwd: shapes")
+    n, h, ww, c = a.shape
+    hw = h * ww
+    blocks = L.lib().pti_lpips_tap_nhwc_blocks(c, hw)
+    if blocks <= 0:
+        raise ValueError(f"lpips_tap_nhwc_fwd: unsupported channel count {c}")
+    saved = torch.empty(n, 3, hw, dtype=F32, device=a.device)
+    part = torch.empty(n, blocks, dtype=F32, device=a.device)
+    L.check(L.lib().pti_lpips_tap_nhwc_fwd(_ptr(a), _ptr(b), _ptr(w), _ptr(saved), _ptr(part), n, c, hw, _stream()),
+            "pti_lpips_tap_nhwc_fwd")
+    return part.sum(1) / hw, saved
+
+
+def lpips_tap_nhwc_bwd(a, b, w, saved, gout):
+    """-> d(sum_i gout_i * value_i) / d a as NHWC bf16."""
+    _chk(a, F16, "a", 4)
+    _chk(b, F16, "b", 4)
+    _chk(gout, F32, "gout", 1)
+    n, h, ww, c = a.shape
+    if a.shape != b.shape or tuple(saved.shape) != (n, 3, h * ww) or gout.numel() != n or w.numel() != c:
+        raise ValueError("lpips_tap_nhwc_bwd: shapes")
+    ga = torch.empty(a.shape, dtype=BF16, device=a.device)
+    L.check(L.lib().pti_lpips_tap_nhwc_bwd(_ptr(a), _ptr(b), _ptr(w), _ptr(saved), _ptr(gout), _ptr(ga), n, c, h * ww, _stream()),
+            "pti_lpips_tap_nhwc_bwd")
+    return ga
+
+
+def squeeze_conv1_fwd(x, w10):
+    """x fp32 [n, 1, h, w] (or [n, h, w]) -> tap 0 of the perceptual network, fp16 [n, (h-3)//2+1, (w-3)//2+1, 64];
+    w10: the folded first layer, fp32 [10, 64] (perceptual_engine.fold_first_layer)."""
+    _chk(x, F32, "x")
+    _chk(w10, F32, "w10")
+    if x.dim() == 4 and x.shape[1] == 1:
+        x = x[:, 0]
+    if x.dim() != 3 or w10.numel() != 640:
+        raise ValueError("squeeze_conv1_fwd: expected a one-channel image batch and a [10, 64] table")
+    n, h, w = x.shape
+    y = torch.empty(n, (h - 3) // 2 + 1, (w - 3) // 2 + 1, 64, dtype=F16, device=x.device)
+    L.check(L.lib().pti_squeeze_conv1_fwd(_ptr(x), _ptr(w10), _ptr(y), n, h, w, _stream()), "pti_squeeze_conv1_fwd")
+    return y
+
+
+def squeeze_conv1_bwd(g, t0, w10, h, w):
+    """g bf16 [n, ho, wo, 64] (gradient w.r.t. tap 0), t0 = the forward's output -> dx fp32 [n, 1, h, w]."""
+    _chk(g, BF16, "g", 4)
+    _chk(t0, F16, "t0", 4)
+    _chk(w10, F32, "w10")
+    n = g.shape[0]
+    if g.shape != t0.shape or tuple(g.shape[1:]) != ((h - 3) // 2 + 1, (w - 3) // 2 + 1, 64):
+        raise ValueError("squeeze_conv1_bwd: shapes")
+    dx = torch.empty(n, 1, h, w, dtype=F32, device=g.device)
+    L.check(L.lib().pti_squeeze_conv1_bwd(_ptr(g), _ptr(t0), _ptr(w10), _ptr(dx), n, h, w, _stream()), "pti_squeeze_conv1_bwd")
+    return dx

@@ -30,6 +30,22 @@ _PLAN = (("pool",), ("fire", 3, False), ("fire", 4, True), ("pool",), ("fire", 6
          ("fire", 9, True), ("fire", 10, True), ("fire", 11, True), ("fire", 12, True))
 
 
+def fold_first_layer(net):
+    """The first convolution of the network for a ONE-channel image (the reference repeats it three times,
+    ``utils/losses.py:8-28``, and lpips' ScalingLayer scales every copy): fp32 [10, 64] = {W'[tap][co] =
+    sum_c W[co][c][tap] / scale_c, b'[co] = b[co] - sum_c shift_c / scale_c * sum_tap W[co][c][tap]} -- exact, the layer
+    has no padding.  Operand of ``ops.squeeze_conv1_fwd`` / ``_bwd``."""
+    conv = net.features[0]
+    if conv.in_channels != 3 or conv.out_channels != 64 or tuple(conv.kernel_size) != (3, 3) or tuple(conv.stride) != (2, 2) \
+            or tuple(conv.padding) != (0, 0):
+        raise ValueError("fold_first_layer: expected squeezenet1_1's first convolution (3 -> 64, 3x3, stride 2, no padding)")
+    w = conv.weight.detach().double()                                    # [64, 3, 3, 3]
+    scale, shift = net.scale.detach().double().view(3), net.shift.detach().double().view(3)
+    wf = (w / scale.view(1, 3, 1, 1)).sum(1).reshape(64, 9)               # [co][tap]
+    bf = conv.bias.detach().double() - (w.sum((2, 3)) * (shift / scale).view(1, 3)).sum(1)
+    return torch.cat([wf.t().contiguous(), bf.view(1, 64)], 0).float().contiguous()
+
+
 class _Fire:
     def __init__(self, f):
         dev = f.squeeze.weight.device
@@ -78,21 +94,7 @@ class SqueezeTrunk:
     def __init__(self, net):
         self.fires = {i: _Fire(net.features[i]) for st in _PLAN if st[0] == "fire" for i in (st[1],)}
         self.c0 = net.features[0].out_channels
-
-    @staticmethod
-    def to_nhwc_f16(t0):
-        """tap 0 as torch leaves it (NCHW fp32) -> NHWC fp16."""
-        return t0.to(F16).contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
-
-    @staticmethod
-    def to_nchw_f32(x):
-        """NHWC 16-bit -> NCHW fp32 contiguous (the layout of the comparison kernels)."""
-        return x.permute(0, 3, 1, 2).float().contiguous()
-
-    @staticmethod
-    def to_nhwc_bf16(g):
-        """NCHW fp32 gradient -> NHWC bf16."""
-        return g.to(BF16).contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+        self.w10 = fold_first_layer(net)
 
     def forward(self, x0, save: bool):
         """x0: NHWC fp16 [N, H, W, 64] (ReLU output of the first convolution) -> (taps 1..6 as NHWC fp16, saved)."""

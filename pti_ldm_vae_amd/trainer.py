@@ -259,17 +259,19 @@ class VAETrainer:
         """train_vae.py:395-397: p_loss = loss_perceptual(ensure_three_channels(recon), ensure_three_channels(images));
         adds perceptual_weight * d p_loss / d recon into ``d_recon`` (when given).  ``target``: what
         ``_perceptual_target_taps(images)`` returned at the start of the step."""
-        from .utils.losses import ensure_three_channels
+        from .utils.losses import ensure_three_channels as three
+        if hasattr(self.perceptual, "from_taps"):     # this package's module repeats the channel itself -- and takes
+            three = lambda t: t                       # one-channel images through its folded first layer  # noqa: E731
         if d_recon is None:
             with torch.no_grad():
-                return self.perceptual(ensure_three_channels(recon.float()), ensure_three_channels(images.float()))
+                return self.perceptual(three(recon.float()), three(images.float()))
         r = recon.detach().requires_grad_(True)
         with torch.enable_grad():
             if target is not None:
                 torch.cuda.current_stream().wait_event(target[1])
-                p = self.perceptual.from_taps(ensure_three_channels(r.float()), target[0])
+                p = self.perceptual.from_taps(three(r.float()), target[0])
             else:
-                p = self.perceptual(ensure_three_channels(r.float()), ensure_three_channels(images.float()))
+                p = self.perceptual(three(r.float()), three(images.float()))
             (g,) = torch.autograd.grad(p, r)
         d_recon.add_(g, alpha=self.perceptual_weight)
         return p.detach()

@@ -201,6 +201,7 @@ def test_whole_term_native_trunk_vs_torch_network(dev):
     y = torch.rand(3, 1, 256, 256, generator=g).to(dev)
     x = (y + 0.1 * torch.randn(3, 1, 256, 256, generator=g).to(dev)).requires_grad_(True)
     assert pl.net.use_native(x)
+    y, x = y.repeat(1, 3, 1, 1), x.detach().repeat(1, 3, 1, 1).requires_grad_(True)     # three-channel route: torch first layer
     l1 = pl(x, y)
     g1, = torch.autograd.grad(l1, x)
     l2 = ref(x, y)
@@ -214,3 +215,99 @@ def test_whole_term_native_trunk_vs_torch_network(dev):
     assert l3.item() == l1.item()
     # identical images: exactly zero
     assert pl(y, y).item() == 0.0
+
+
+@pytest.mark.parametrize("shape", [(3, 128, 63, 63), (2, 256, 31, 31), (4, 384, 15, 15), (2, 512, 15, 15), (1, 64, 5, 7), (2, 1024, 3, 3)])
+def test_tap_nhwc_kernels_vs_torch_float64(dev, shape):
+    """The comparison kernels on the trunk's layout (NHWC fp16 maps, bf16 gradient) vs the torch formula in float64 on the
+    SAME fp16-rounded values: value 1e-5 relative; gradient rel-L2 3e-3 (one bf16 rounding of the result)."""
+    from pti_ldm_vae_amd import ops
+    from pti_ldm_vae_amd.models.perceptual import lpips_tap_torch
+    a, b, wt = _inputs(shape, seed=sum(shape) + 1)
+    a, b = a.half(), b.half()
+    a64 = a.double().requires_grad_(True)
+    v64 = lpips_tap_torch(a64, b.double(), wt.double().view(1, -1, 1, 1))
+    gout = torch.linspace(0.5, 1.5, shape[0], dtype=torch.float64)
+    g64, = torch.autograd.grad((v64 * gout).sum(), a64)
+    an = a.permute(0, 2, 3, 1).contiguous().to(dev)
+    bn = b.permute(0, 2, 3, 1).contiguous().to(dev)
+    v, sv = ops.lpips_tap_nhwc_fwd(an, bn, wt.to(dev))
+    ga = ops.lpips_tap_nhwc_bwd(an, bn, wt.to(dev), sv, gout.float().to(dev))
+    relv = ((v.cpu().double() - v64).abs() / v64.abs().clamp_min(1e-12)).max().item()
+    relg = _rel(ga.cpu().permute(0, 3, 1, 2).float(), g64)
+    print(f"[lpips tap nhwc {shape}] value rel {relv:.2e}, grad relL2 {relg:.2e}")
+    assert relv <= 1e-5 and relg <= 3e-3
+    v0, _ = ops.lpips_tap_nhwc_fwd(an, an.clone(), wt.to(dev))
+    assert float(v0.abs().max()) == 0.0
+    assert not ops.lpips_tap_nhwc_supported(40) and ops.lpips_tap_nhwc_supported(384)
+
+
+def test_layout_kernels_at_the_trunk_boundary(dev):
+    from pti_ldm_vae_amd import ops
+    g = torch.Generator().manual_seed(2)
+    for n, c, h, w in ((2, 64, 127, 127), (1, 128, 5, 9), (3, 64, 1, 1)):
+        x = torch.randn(n, c, h, w, generator=g).to(dev)
+        y = ops.nchw_f32_to_nhwc_f16(x)
+        assert torch.equal(y, x.permute(0, 2, 3, 1).half())
+        gr = torch.randn(n, h, w, c, generator=g).to(dev).bfloat16()
+        base = torch.randn(n, c, h, w, generator=g).to(dev)
+        out = ops.nhwc_bf16_add_to_nchw_f32_(gr, base.clone())
+        assert torch.equal(out, base + gr.permute(0, 3, 1, 2).float())
+    with pytest.raises((ValueError, TypeError, RuntimeError)):
+        ops.nchw_f32_to_nhwc_f16(torch.zeros(1, 48, 4, 4, device=dev))
+
+
+def test_folded_first_layer_vs_torch(dev):
+    """The first layer for a one-channel image (three scaled copies folded into a 1 -> 64 convolution, ReLU fused) vs the
+    torch layers on the repeated, scaled image: forward rel-L2 1e-3 (fp16 output), gradient w.r.t. the one-channel
+    image rel-L2 5e-3 (bf16 incoming gradient)."""
+    from pti_ldm_vae_amd import ops
+    from pti_ldm_vae_amd.models.perceptual import SqueezeLPIPS
+    from pti_ldm_vae_amd.perceptual_engine import fold_first_layer
+    from pti_ldm_vae_amd.utils.losses import ensure_three_channels
+    torch.manual_seed(6)
+    net = SqueezeLPIPS().to(dev)
+    for n, h, w in ((2, 256, 256), (1, 17, 30), (3, 3, 3)):
+        x = torch.rand(n, 1, h, w, device=dev)
+        xt = x.clone().requires_grad_(True)
+        t0 = net.tap0(ensure_three_channels(xt))                     # [n, 64, ho, wo] fp32
+        w10 = fold_first_layer(net)
+        y = ops.squeeze_conv1_fwd(x, w10)
+        assert tuple(y.shape) == (n, t0.shape[2], t0.shape[3], 64)
+        r_f = _rel(y.permute(0, 3, 1, 2).float(), t0.detach())
+        # the incoming gradient is zero where the fp32 and the fp16 outputs may disagree about the sign (|t0| tiny)
+        gy = torch.randn_like(t0) * (t0.detach() > 1e-2)
+        gxt, = torch.autograd.grad(t0, xt, gy)
+        dx = ops.squeeze_conv1_bwd(gy.permute(0, 2, 3, 1).contiguous().bfloat16(), y, w10, h, w)
+        r_g = _rel(dx, gxt)
+        print(f"[first layer {n}x{h}x{w}] forward relL2 {r_f:.2e}, gradient relL2 {r_g:.2e}")
+        assert r_f <= 1e-3 and r_g <= 5e-3
+
+
+def test_whole_term_one_channel_path_vs_torch_network(dev):
+    """One-channel images through PerceptualLoss: everything on the HIP library (folded first layer, trunk, comparison)
+    vs the torch network + torch tail on the repeated image."""
+    import copy
+    from pti_ldm_vae_amd.models import PerceptualLoss
+    torch.manual_seed(3)
+    pl = PerceptualLoss(allow_random_init=True).to(dev)
+    ref = copy.deepcopy(pl)
+    ref.net.native_trunk = False
+    ref.net.fused_tail = False
+    g = torch.Generator().manual_seed(4)
+    y = torch.rand(3, 1, 256, 256, generator=g).to(dev)
+    x = (y + 0.1 * torch.randn(3, 1, 256, 256, generator=g).to(dev)).requires_grad_(True)
+    assert pl._one_channel_native(x)
+    l1 = pl(x, y)
+    g1, = torch.autograd.grad(l1, x)
+    l2 = ref(x, y)
+    g2, = torch.autograd.grad(l2, x)
+    cos = torch.nn.functional.cosine_similarity(g1.flatten().double(), g2.flatten().double(), dim=0).item()
+    print(f"[lpips term, one-channel path] {l1.item():.6e} vs torch {l2.item():.6e}; grad cosine {cos:.6f}, relL2 {_rel(g1, g2):.2e}")
+    assert l1.item() == pytest.approx(l2.item(), rel=5e-3)
+    assert cos >= 0.999 and tuple(g1.shape) == (3, 1, 256, 256) and torch.isfinite(g1).all()
+    assert pl.from_taps(x, pl.target_taps(y)).item() == l1.item()
+    assert pl(y, y).item() == 0.0
+    # three-channel inputs keep the torch first layer + HIP trunk
+    x3 = x.detach().repeat(1, 3, 1, 1)
+    assert pl(x3, y.repeat(1, 3, 1, 1)).item() == pytest.approx(l2.item(), rel=5e-3)
