@@ -76,6 +76,9 @@ typedef struct pti_conv_desc {
   /* (v_mfma_f32_32x32x16_f16; same rate as bf16, 8x finer operand rounding).  Needs in_f16 = out_f16 = 1 (and      */
   /* res_f16 when a residual is added): the forward convs on fp16 storage.  Gradients always use bf16 operands.     */
   int32_t w_f16;
+  /* pti_conv2d_mfma only: y = max(conv + bias [+ residual], 0) -- the ReLU of the perceptual network's Fire modules  */
+  /* fused into the store.  Plain fp16 forward launches (w_f16, no prologue, stride-1 gather); refused elsewhere.     */
+  int32_t relu_out;
 } pti_conv_desc;
 
 int pti_abi_version(void);

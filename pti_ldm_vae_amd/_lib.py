@@ -27,7 +27,7 @@ class ConvDesc(C.Structure):
         ("eps", C.c_float), ("in_f32", C.c_int32), ("out_f32", C.c_int32),
         ("in_stride", C.c_int64 * 4), ("out_stride", C.c_int64 * 4),
         ("in_f16", C.c_int32), ("res_f16", C.c_int32), ("out_f16", C.c_int32), ("pool2x2_out", C.c_int32),
-        ("w_f16", C.c_int32),
+        ("w_f16", C.c_int32), ("relu_out", C.c_int32),
     ]
 
 

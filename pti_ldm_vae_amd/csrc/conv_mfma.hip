@@ -85,6 +85,7 @@ struct ConvArgs {
   // 16-bit storage format of x / residual (or the GN input of the fused backward) / y: 0 = bf16, 1 = fp16
   int in_f16, res_f16, out_f16;
   int pool2;   // v2 kernel: store the 2x2-sum-pooled output tile [N][Ho/2][Wo/2][Cout] (data gradient of nearest-2x up-sampling)
+  int relu_out;   // y = max(y, 0) in the epilogue (plain fp16 forward launches only: the perceptual network's Fire convs)
   int w_f16;   // packed weights are IEEE fp16 and the MFMA runs v_mfma_f32_32x32x16_f16 on fp16 operands (forward convs on fp16 storage)
 };
 
@@ -802,6 +803,9 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
         unpack2f(rr[1], res_f16, e2, e3);
         v0 += e0; v1 += e1; v2 += e2; v3 += e3;
       }
+      if constexpr (FM == 1 && PRO == PTI_PRO_NONE) {   // the only instantiation that carries the fused ReLU
+        if (a.relu_out) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+      }
       const u32x2 packed = pack4f(v0, v1, v2, v3, out_f16);
       *(u32x2*)ep = packed;
       if (do_stats && inb) {
@@ -922,6 +926,7 @@ int launch2_cfg(ConvArgs a, hipStream_t st) {
   const bool fwd_plain = fm == 1 && a.prologue == PTI_PRO_NONE && !a.gn_mode && !a.pool2;
   const bool dgrad = fm == 2 && a.prologue == PTI_PRO_NONE && !a.gn_mode && !a.out_stats;
   const bool dgrad_gn = fm == 3 && a.prologue == PTI_PRO_NONE && a.gn_mode && !a.out_stats && !a.pool2;
+  if (a.relu_out && !(fwd_plain && !a.act_out)) return 3;   // only that kernel has the fused ReLU
   // forward GroupNorm+SiLU launches: the prologue is a compile-time constant only for the 2-workgroup/CU shapes; at
   // the 128-VGPR cap of the others it made the compiler interleave the SiLU chains and spill (32->32@256^2 +res+stats
   // 153 -> 184 us), so those keep the run-time prologue flag (but the compile-time formats).  (tried: 3 workgroups/CU
@@ -1174,6 +1179,9 @@ static int conv2d_mfma_impl(const void* x, const void* w_packed, const float* bi
   a.in_f16 = d->in_f16; a.res_f16 = d->res_f16; a.out_f16 = d->out_f16;
   a.pool2 = d->pool2x2_out;
   a.w_f16 = d->w_f16;
+  a.relu_out = d->relu_out;
+  if (a.relu_out && (gf || d->mode == PTI_CONV_S2PAD))
+    PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: relu_out is for plain fp16 forward launches (stride-1 gather, no prologue)");
   if (a.w_f16 && !(d->in_f16 && d->out_f16 && (d->res_f16 || !d->add_residual)) )
     PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: fp16-packed weights need fp16 input, output and residual (the forward convs)");
   if (a.w_f16 && (gf || d->pool2x2_out))
@@ -1204,6 +1212,7 @@ static int conv2d_mfma_impl(const void* x, const void* w_packed, const float* bi
     ck = pick_ck2(d->cin, cout_tile);
     rc = d->ksize == 1 ? launch2<1>(a, ck, cout_tile, (hipStream_t)s) : launch2<3>(a, ck, cout_tile, (hipStream_t)s);
   }
+  if (rc == 3) PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: relu_out needs a plain fp16 forward launch (w_f16, fp16 in/out, no prologue, no side output)");
   if (rc == 2) PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: no fp16-operand kernel for this launch (w_f16 with this prologue / epilogue)");
   if (rc != 0) PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: no kernel for ck=%d cout_tile=%d", ck, cout_tile);
   PTI_CHECK_LAUNCH("conv2d_mfma");

@@ -108,9 +108,10 @@ def gn_stats(x, groups, stats=None):
 
 def conv_mfma(x, w_packed, bias, y, *, cout, ksize=3, mode=PTI_CONV_S1, prologue=PTI_PRO_NONE, in_stats=None,
               gamma=None, beta=None, groups=0, eps=1e-6, residual=None, out_stats=None, out_groups=0, act_out=None,
-              pool2=False):
+              pool2=False, relu=False):
     """``act_out`` (optional, bf16, x's shape): also write prologue(x) for the weight-gradient pass to reuse.
-    ``pool2``: y is [n, ho/2, wo/2, cout], the 2x2 sum pool of the conv output (fused nearest-2x up-sampling backward)."""
+    ``pool2``: y is [n, ho/2, wo/2, cout], the 2x2 sum pool of the conv output (fused nearest-2x up-sampling backward).
+    ``relu``: y = max(conv + bias, 0) (plain fp16 forward launches: the perceptual network's Fire modules)."""
     _chk(x, ACT16, "x", 4)
     _chk(y, ACT16, "y", 4)
     n, h, w, cin = x.shape
@@ -145,7 +146,7 @@ def conv_mfma(x, w_packed, bias, y, *, cout, ksize=3, mode=PTI_CONV_S1, prologue
                  groups=groups, add_residual=int(residual is not None), accum_stats=int(out_stats is not None),
                  out_groups=out_groups, eps=eps, in_f16=int(x.dtype == F16),
                  res_f16=int(residual is not None and residual.dtype == F16), out_f16=int(y.dtype == F16),
-                 pool2x2_out=int(pool2), w_f16=int(w_f16))
+                 pool2x2_out=int(pool2), w_f16=int(w_f16), relu_out=int(relu))
     prof = KERNEL_PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

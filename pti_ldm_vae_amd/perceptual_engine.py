@@ -8,7 +8,8 @@ convolution on the HIP library:
   * a Fire module = squeeze 1x1 + ReLU, then expand1x1 and expand3x3 + ReLU, concatenated.  Here: ONE 1x1
     ``pti_conv2d_mfma`` (squeeze channels zero-padded to a multiple of 32) and ONE 3x3 ``pti_conv2d_mfma`` whose first
     half of output channels carries the 1x1 expand weights at the centre tap -- the concatenation is the output layout;
-  * ReLU / ReLU-backward / MaxPool(3, 2, ceil) forward + backward: ``csrc/squeeze.hip``;
+  * ReLU fused into the convolutions' stores (``relu_out``); ReLU-backward / MaxPool(3, 2, ceil) forward + backward and
+    the first layer folded to one input channel: ``csrc/squeeze.hip``;
   * activations NHWC fp16 (forward MFMA operands fp16, as the VAE's forward), gradients NHWC bf16 through the same
     data-gradient kernels as the VAE's backward (transposed / flipped weight packs).  The network is frozen: no weight
     gradients, weights packed once.
@@ -69,11 +70,9 @@ class _Fire:
     def fwd(self, x):
         n, h, w, _ = x.shape
         s = torch.empty(n, h, w, self.sp, dtype=F16, device=x.device)
-        ops.conv_mfma(x, self.wsq, self.bsq, s, cout=self.sp, ksize=1)
-        ops.relu_f16_(s)
+        ops.conv_mfma(x, self.wsq, self.bsq, s, cout=self.sp, ksize=1, relu=True)      # ReLU fused into the store
         e = torch.empty(n, h, w, self.cout, dtype=F16, device=x.device)
-        ops.conv_mfma(s, self.wex, self.bex, e, cout=self.cout, ksize=3)
-        ops.relu_f16_(e)
+        ops.conv_mfma(s, self.wex, self.bex, e, cout=self.cout, ksize=3, relu=True)
         return s, e
 
     def bwd(self, ge, s, e):

@@ -311,3 +311,24 @@ def test_whole_term_one_channel_path_vs_torch_network(dev):
     # three-channel inputs keep the torch first layer + HIP trunk
     x3 = x.detach().repeat(1, 3, 1, 1)
     assert pl(x3, y.repeat(1, 3, 1, 1)).item() == pytest.approx(l2.item(), rel=5e-3)
+
+
+def test_fused_relu_store_of_the_plain_forward_conv(dev):
+    """``relu_out``: y = max(conv + bias, 0) in the store of the plain fp16 forward convolution -- bit-equal to the same
+    launch followed by the separate ReLU pass; refused on launches whose kernel does not carry it."""
+    from pti_ldm_vae_amd import ops
+    g = torch.Generator().manual_seed(8)
+    for cin, cout, k, hw in ((64, 32, 1, 63), (32, 128, 3, 31), (64, 512, 3, 15)):
+        w = (torch.randn(cout, cin, k, k, generator=g) * 0.1).to(dev)
+        b = torch.randn(cout, generator=g).to(dev)
+        x = torch.randn(2, hw, hw, cin, generator=g).half().to(dev)
+        wp = ops.pack_conv_weight(w, k, f16=True)
+        y0 = torch.empty(2, hw, hw, cout, dtype=torch.float16, device=dev)
+        y1 = torch.empty_like(y0)
+        ops.conv_mfma(x, wp, b, y0, cout=cout, ksize=k)
+        ops.conv_mfma(x, wp, b, y1, cout=cout, ksize=k, relu=True)
+        assert torch.equal(y1, ops.relu_f16_(y0.clone())) and (y0 < 0).any()
+    wpb = ops.pack_conv_weight(w, k)                                   # bf16 pack: a data-gradient style launch
+    with pytest.raises(RuntimeError):
+        ops.conv_mfma(x.bfloat16(), wpb, None, torch.empty(2, hw, hw, cout, dtype=torch.bfloat16, device=dev), cout=cout, ksize=k,
+                      relu=True)
