@@ -10,9 +10,10 @@ for b in 8 32; do
 done
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --adv > gpurun_out/r2_final_A_adv.json 2>/dev/null
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --perceptual > gpurun_out/r2_final_A_perc.json 2>/dev/null
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --adv --perceptual > gpurun_out/r2_final_A_full.json 2>/dev/null
 python bench.py --steps 15 --warmup 4 --no-cpu-baseline --adv --config $A --batch 8 > gpurun_out/r2_final_AR8_adv.json 2>/dev/null
 python bench.py --steps 15 --warmup 4 --no-cpu-baseline --adv --perceptual --config $A --batch 8 > gpurun_out/r2_final_AR8_full.json 2>/dev/null
-for f in A AR8 AR32 reg8 reg32 A_adv A_perc AR8_adv AR8_full; do
+for f in A AR8 AR32 reg8 reg32 A_adv A_perc A_full AR8_adv AR8_full; do
   python -c "
 import json
 d=json.loads(open('gpurun_out/r2_final_$f.json').read().strip().splitlines()[-1]); print('$f', d['ms_per_step'], d['value'], d.get('model_tflops_per_gpu'))"
