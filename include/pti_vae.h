@@ -368,6 +368,7 @@ int pti_lpips_tap_bwd(const float* a, const float* b, const float* w, const floa
  * data gradient); activations NHWC fp16, gradients NHWC bf16, element counts / channels multiples of 8.
  *   pti_relu_f16:        x = max(x, 0) in place.
  *   pti_relu_bwd:        g = y > 0 ? g : 0 in place (y = the ReLU OUTPUT).
+ *   pti_relu_bwd_add:    g = y > 0 ? g + g2 : 0 in place (a tap's own gradient + the one arriving from later layers).
  *   pti_maxpool3s2_out:  pooled size of one spatial dimension.
  *   pti_maxpool3s2_fwd:  y [n][ho][wo][c] = max over the (clipped) 3x3 windows of x [n][h][w][c].
  *   pti_maxpool3s2_bwd:  gx (+)= gather of gy over the windows whose maximum the element is (no atomics).
@@ -381,9 +382,10 @@ int pti_lpips_tap_bwd(const float* a, const float* b, const float* w, const floa
  *                        into a 1 -> 64 convolution: w10 fp32 [10][64] = {W'[tap][co] = sum_c W[co][c][tap] / scale_c,
  *                        b'[co] = b[co] - sum_c shift_c / scale_c * sum_tap W[co][c][tap]}.  x fp32 [n][h][w];
  *                        fwd: y fp16 [n][(h-3)/2+1][(w-3)/2+1][64] = tap 0;  bwd: dx fp32 [n][h][w] from the bf16
- *                        gradient g w.r.t. tap 0 (ReLU mask taken from t0 = y).                                          */
+ *                        gradient g w.r.t. tap 0 (ReLU mask taken from t0 = y; t0 = NULL: g is already masked).           */
 int pti_relu_f16(void* x, int64_t count, pti_stream_t s);
 int pti_relu_bwd(void* g, const void* y, int64_t count, pti_stream_t s);
+int pti_relu_bwd_add(void* g, const void* g2, const void* y, int64_t count, pti_stream_t s);
 int pti_maxpool3s2_out(int h);
 int pti_maxpool3s2_fwd(const void* x, void* y, int n, int h, int w, int c, pti_stream_t s);
 int pti_maxpool3s2_bwd(const void* gy, const void* x, const void* y, void* gx, int n, int h, int w, int c, int accumulate,

@@ -101,6 +101,7 @@ SIGNATURES = {
     "pti_lpips_tap_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "pti_relu_f16": (_I, [_P, _I64, _P]),
     "pti_relu_bwd": (_I, [_P, _P, _I64, _P]),
+    "pti_relu_bwd_add": (_I, [_P, _P, _P, _I64, _P]),
     "pti_maxpool3s2_out": (_I, [_I]),
     "pti_maxpool3s2_fwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "pti_maxpool3s2_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -36,6 +36,20 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(u32x4* __restrict__ g, co
   g[i] = gv;
 }
 
+// g = y > 0 ? g + g2 : 0   (the tap's own gradient + the gradient arriving from the layers after it, then the mask)
+__global__ __launch_bounds__(256) void relu_bwd_add_kernel(u32x4* __restrict__ g, const u32x4* __restrict__ g2,
+                                                           const u32x4* __restrict__ y, long long n8) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const f16x8 yv = __builtin_bit_cast(f16x8, y[i]);
+  float a[8], b[8];
+  unpack8(g[i], a);
+  unpack8(g2[i], b);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = yv[j] > (_Float16)0 ? a[j] + b[j] : 0.f;
+  g[i] = pack8(a);
+}
+
 // MaxPool2d(3, 2, ceil_mode=True) on NHWC fp16: thread = (output pixel, 8-channel piece); windows are clipped to the map
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ y, int H,
                                                           int W, int Ho, int Wo, int NC, long long total) {
@@ -212,11 +226,16 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const u32x4* __restrict_
         const long long o = (((n * Ho + oh) * Wo + ow) << 3) + pc;
         float gv[8];
         unpack8(g[o], gv);
-        const f16x8 tv = __builtin_bit_cast(f16x8, t0[o]);
         const float* wr = wl + (dh * 3 + dw) * 64 + pc * 8;
+        if (t0) {   // ReLU mask from the forward's output (nullptr: g is already masked)
+          const f16x8 tv = __builtin_bit_cast(f16x8, t0[o]);
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (tv[j] > (_Float16)0) acc += gv[j] * wr[j];
+          for (int j = 0; j < 8; ++j)
+            if (tv[j] > (_Float16)0) acc += gv[j] * wr[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc += gv[j] * wr[j];
+        }
       }
     }
   }
@@ -249,6 +268,16 @@ extern "C" int pti_relu_bwd(void* g, const void* y, int64_t count, pti_stream_t 
   PTI_LAUNCH(relu_bwd_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)s, (u32x4*)g,
              (const u32x4*)y, n8);
   PTI_CHECK_LAUNCH("relu_bwd");
+  return PTI_OK;
+}
+
+extern "C" int pti_relu_bwd_add(void* g, const void* g2, const void* y, int64_t count, pti_stream_t s) {
+  if (!g || !g2 || !y || count <= 0 || count % 8)
+    PTI_FAIL(PTI_EINVAL, "relu_bwd_add: count %lld must be a positive multiple of 8", (long long)count);
+  const long long n8 = count / 8;
+  PTI_LAUNCH(relu_bwd_add_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)s, (u32x4*)g,
+             (const u32x4*)g2, (const u32x4*)y, n8);
+  PTI_CHECK_LAUNCH("relu_bwd_add");
   return PTI_OK;
 }
 
@@ -305,7 +334,7 @@ extern "C" int pti_squeeze_conv1_fwd(const float* x, const float* w10, void* y, 
 
 extern "C" int pti_squeeze_conv1_bwd(const void* g, const void* t0, const float* w10, float* dx, int n, int h, int w,
                                      pti_stream_t s) {
-  if (!g || !t0 || !w10 || !dx || n <= 0 || h < 3 || w < 3) PTI_FAIL(PTI_EINVAL, "squeeze_conv1_bwd: bad args");
+  if (!g || !w10 || !dx || n <= 0 || h < 3 || w < 3) PTI_FAIL(PTI_EINVAL, "squeeze_conv1_bwd: bad args");
   const int ho = (h - 3) / 2 + 1, wo = (w - 3) / 2 + 1;
   const long long total = (long long)n * h * w * 8;
   PTI_LAUNCH(conv1_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, (const u32x4*)g,

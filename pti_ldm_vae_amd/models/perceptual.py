@@ -151,8 +151,8 @@ class _OneChannelCompareFn(torch.autograd.Function):
         g = g.contiguous().float()
         f, t, w, sv = ctx.feats, ctx.target, ctx.lin_ws, ctx.tails
         tap_grads = [ops.lpips_tap_nhwc_bwd(f[k], t[k], w[k], sv[k], g) for k in range(len(f))]
-        g0 = tap_grads[0].add_(ctx.trunk.backward(ctx.saved, tap_grads[1:]))
-        dx = ops.squeeze_conv1_bwd(g0, f[0], ctx.trunk.w10, *ctx.hw)
+        g0 = ops.relu_bwd_add_(tap_grads[0], ctx.trunk.backward(ctx.saved, tap_grads[1:]).contiguous(), f[0])
+        dx = ops.squeeze_conv1_bwd(g0, None, ctx.trunk.w10, *ctx.hw)       # g0 carries the ReLU mask already
         ctx.saved = ctx.feats = ctx.tails = None
         return dx, None, None, None
 

@@ -848,6 +848,17 @@ def relu_bwd_(g, y):
     return g
 
 
+def relu_bwd_add_(g, g2, y):
+    """g (bf16) = y > 0 ? g + g2 : 0 in place."""
+    _chk(g, BF16, "g")
+    _chk(g2, BF16, "g2")
+    _chk(y, F16, "y")
+    if g.shape != y.shape or g2.shape != y.shape:
+        raise ValueError("relu_bwd_add_: shapes")
+    L.check(L.lib().pti_relu_bwd_add(_ptr(g), _ptr(g2), _ptr(y), g.numel(), _stream()), "pti_relu_bwd_add")
+    return g
+
+
 def maxpool3s2_fwd(x):
     """MaxPool2d(3, 2, ceil_mode=True) on NHWC fp16."""
     _chk(x, F16, "x", 4)
@@ -949,12 +960,14 @@ def squeeze_conv1_fwd(x, w10):
 
 
 def squeeze_conv1_bwd(g, t0, w10, h, w):
-    """g bf16 [n, ho, wo, 64] (gradient w.r.t. tap 0), t0 = the forward's output -> dx fp32 [n, 1, h, w]."""
+    """g bf16 [n, ho, wo, 64] (gradient w.r.t. tap 0), t0 = the forward's output (None: g already carries the ReLU
+    mask) -> dx fp32 [n, 1, h, w]."""
     _chk(g, BF16, "g", 4)
-    _chk(t0, F16, "t0", 4)
     _chk(w10, F32, "w10")
     n = g.shape[0]
-    if g.shape != t0.shape or tuple(g.shape[1:]) != ((h - 3) // 2 + 1, (w - 3) // 2 + 1, 64):
+    if t0 is not None:
+        _chk(t0, F16, "t0", 4)
+    if (t0 is not None and g.shape != t0.shape) or tuple(g.shape[1:]) != ((h - 3) // 2 + 1, (w - 3) // 2 + 1, 64):
         raise ValueError("squeeze_conv1_bwd: shapes")
     dx = torch.empty(n, 1, h, w, dtype=F32, device=g.device)
     L.check(L.lib().pti_squeeze_conv1_bwd(_ptr(g), _ptr(t0), _ptr(w10), _ptr(dx), n, h, w, _stream()), "pti_squeeze_conv1_bwd")

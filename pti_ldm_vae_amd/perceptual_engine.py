@@ -75,10 +75,15 @@ class _Fire:
         ops.conv_mfma(s, self.wex, self.bex, e, cout=self.cout, ksize=3, relu=True)
         return s, e
 
-    def bwd(self, ge, s, e):
-        """ge: gradient w.r.t. the module's (post-ReLU) output, consumed in place -> gradient w.r.t. its input."""
+    def bwd(self, ge, s, e, g_next=None):
+        """ge: gradient w.r.t. the module's (post-ReLU) output, consumed in place (``g_next``: a second gradient of the
+        same output to be added first -- a tap's own gradient + the one from the layers after it) -> gradient w.r.t.
+        its input."""
         n, h, w, _ = e.shape
-        ops.relu_bwd_(ge, e)
+        if g_next is not None:
+            ops.relu_bwd_add_(ge, g_next, e)
+        else:
+            ops.relu_bwd_(ge, e)
         gs = torch.empty(n, h, w, self.sp, dtype=BF16, device=e.device)
         ops.conv_mfma(ge, self.wex_t, None, gs, cout=self.sp, ksize=3)
         ops.relu_bwd_(gs, s)
@@ -124,11 +129,9 @@ class SqueezeTrunk:
             else:
                 _, idx, is_tap, s, e = st
                 if is_tap:
-                    ge = tap_grads[k]
+                    ge, g_next = tap_grads[k], g
                     k -= 1
-                    if g is not None:
-                        ge.add_(g)
                 else:
-                    ge = g
-                g = self.fires[idx].bwd(ge, s, e)
+                    ge, g_next = g, None
+                g = self.fires[idx].bwd(ge, s, e, g_next)
         return g

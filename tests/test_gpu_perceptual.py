@@ -155,6 +155,9 @@ def test_relu_passes(dev):
     gr = torch.randn(3, 5, 7, 16, generator=g).to(dev).bfloat16()
     out = ops.relu_bwd_(gr.clone(), y)
     assert torch.equal(out, torch.where(y > 0, gr, torch.zeros_like(gr)))
+    g2 = torch.randn(3, 5, 7, 16, generator=g).to(dev).bfloat16()
+    out2 = ops.relu_bwd_add_(gr.clone(), g2, y)
+    assert torch.equal(out2, torch.where(y > 0, (gr.float() + g2.float()).bfloat16(), torch.zeros_like(gr)))
     with pytest.raises((ValueError, TypeError, RuntimeError)):
         ops.relu_f16_(torch.zeros(7, device=dev).half())          # not a multiple of 8
 
@@ -280,6 +283,10 @@ def test_folded_first_layer_vs_torch(dev):
         gxt, = torch.autograd.grad(t0, xt, gy)
         dx = ops.squeeze_conv1_bwd(gy.permute(0, 2, 3, 1).contiguous().bfloat16(), y, w10, h, w)
         r_g = _rel(dx, gxt)
+        # a gradient that already carries the mask (what the term's backward hands over): same result without t0
+        gm = ops.relu_bwd_(gy.permute(0, 2, 3, 1).contiguous().bfloat16(), y)
+        # (equal up to fp32 summation order: the two branches of the kernel add the eight products differently)
+        assert torch.allclose(ops.squeeze_conv1_bwd(gm, None, w10, h, w), ops.squeeze_conv1_bwd(gm, y, w10, h, w), rtol=1e-4, atol=1e-6)
         print(f"[first layer {n}x{h}x{w}] forward relL2 {r_f:.2e}, gradient relL2 {r_g:.2e}")
         assert r_f <= 1e-3 and r_g <= 5e-3
 
