@@ -339,3 +339,59 @@ def test_fused_relu_store_of_the_plain_forward_conv(dev):
     with pytest.raises(RuntimeError):
         ops.conv_mfma(x.bfloat16(), wpb, None, torch.empty(2, hw, hw, cout, dtype=torch.bfloat16, device=dev), cout=cout, ksize=k,
                       relu=True)
+
+
+def test_train_script_with_local_perceptual_weight_files(dev, tmp_path):
+    """``train_vae --perceptual-weights A B``: the weight files (written here with both packages' key names; random
+    values -- the real ones cannot be fetched) are loaded into the module, the HIP trunk is packed from THEM (not from
+    the constructor's random init), the term is part of the step (``train/perceptual_loss`` logged, > 0) and of the
+    validation pass.  Also: the step with the term is bitwise reproducible."""
+    import json
+    import os
+    from pti_ldm_vae_amd import train_vae
+    from pti_ldm_vae_amd.models import PerceptualLoss, VAEModel
+    from pti_ldm_vae_amd.models.perceptual import SqueezeLPIPS
+    from pti_ldm_vae_amd.trainer import VAETrainer
+    torch.manual_seed(11)
+    src = SqueezeLPIPS()
+    sd = src.state_dict()
+    bb = {k: v for k, v in sd.items() if k.startswith("features.")}
+    bb["classifier.1.weight"] = torch.zeros(1000, 512, 1, 1)            # torchvision's file also holds the classifier
+    lin = {k: v.abs() for k, v in sd.items() if k.startswith("lin")}
+    torch.save(bb, tmp_path / "squeezenet1_1.pth")
+    torch.save(lin, tmp_path / "lpips_squeeze.pth")
+    cfg = json.load(open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "config", "vae_dente_no_adv.json")))
+    cfg["run_dir"] = str(tmp_path / "run")
+    cfg["autoencoder_def"]["channels"] = [32, 64]
+    cfg["autoencoder_def"]["attention_levels"] = [False, False]
+    cfg["autoencoder_def"]["num_res_blocks"] = 1
+    cfg["autoencoder_train"].update(batch_size=2, patch_size=[64, 64], max_epochs=2, perceptual_weight=1.0)
+    cf = tmp_path / "cfg.json"
+    cf.write_text(json.dumps(cfg))
+    train_vae.main(["-c", str(cf), "--synthetic", "8", "--log-every", "1", "--perceptual-weights",
+                    str(tmp_path / "squeezenet1_1.pth"), str(tmp_path / "lpips_squeeze.pth")])
+    lines = [json.loads(l) for l in open(tmp_path / "run" / "metrics.jsonl")]
+    p_train = [l["train/perceptual_loss"] for l in lines if "train/perceptual_loss" in l]
+    assert p_train and all(p > 0 for p in p_train) and any("val/perceptual_loss" in l for l in lines)
+    # the packed trunk follows the loaded weights
+    pl = PerceptualLoss(weights=(str(tmp_path / "squeezenet1_1.pth"), str(tmp_path / "lpips_squeeze.pth"))).to(dev)
+    x = torch.rand(2, 1, 64, 64, device=dev)
+    y = torch.rand(2, 1, 64, 64, device=dev)
+    v_native = pl(x, y).item()
+    pl.net.native_trunk = pl.net.fused_tail = False
+    assert v_native == pytest.approx(pl(x, y).item(), rel=5e-3)
+    # bitwise reproducible step with the term
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(5)
+        m = VAEModel.from_config(dict(spatial_dims=2, in_channels=1, out_channels=1, latent_channels=4, channels=[32, 64],
+                                      num_res_blocks=1, norm_num_groups=16, norm_eps=1e-6, attention_levels=[False, False],
+                                      with_encoder_nonlocal_attn=False, with_decoder_nonlocal_attn=False)).to(dev)
+        p2 = PerceptualLoss(weights=(str(tmp_path / "squeezenet1_1.pth"), str(tmp_path / "lpips_squeeze.pth"))).to(dev)
+        tr = VAETrainer(m, lr=1e-4, perceptual=p2, perceptual_weight=1.0)
+        e = torch.randn(2, 4, 32, 32, generator=torch.Generator().manual_seed(6)).to(dev)
+        for _ in range(2):
+            out = tr.step(x, e)
+        torch.cuda.synchronize()
+        outs.append((out["perceptual"].item(), m.autoencoder.param_arena.detach().clone()))
+    assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1])
