@@ -38,6 +38,8 @@ class DiscEngine:
         self.packed_version = -1
         self._packer = None
         self.wp, self.wpt = [], []
+        # its own split-K workspace: the discriminator step may run on its own stream beside the VAE's weight gradients
+        self.workspace = torch.empty_like(ops.wgrad_workspace(self.dev)) if self.dev.type == "cuda" else None
 
     # ---- weights ---------------------------------------------------------------------------------------------------
     def _w(self, lay, arena):
@@ -154,7 +156,8 @@ class DiscEngine:
             if P is None:
                 raise RuntimeError("PatchDiscriminator.backward: the forward pass was run with save=False")
             if want_wgrad:
-                ops.conv_wgrad_mfma(P, dy, self._w(lay, garena), self._b(lay, garena), ksize=1, accumulate=True)
+                ops.conv_wgrad_mfma(P, dy, self._w(lay, garena), self._b(lay, garena), ksize=1, accumulate=True,
+                                    workspace=self.workspace)
             if i == 0:
                 if d_img is not None:
                     dP = torch.empty_like(P)

@@ -155,6 +155,11 @@ class VAETrainer:
             self.reducer_d = FlatGradAllReducer(discriminator.grad_arena, process_group, bucket_bytes)
             broadcast_parameters(discriminator.param_arena, process_group)
             discriminator.mark_weights_dirty()
+            # the discriminator's own step (losses on fake / real, backward, exchange, Adam) depends on the reconstruction
+            # only: it runs on its own stream beside the VAE backward (PTI_ADV_STREAM=0: after Adam on the main stream)
+            dev_ = discriminator.param_arena.device
+            self._adv_stream = (torch.cuda.Stream(device=dev_)
+                                if dev_.type == "cuda" and os.environ.get("PTI_ADV_STREAM", "1") != "0" else None)
         # perceptual term: any torch module  f(reconstruction, images) -> scalar  on the device (frozen weights)
         self.perceptual, self.perceptual_weight = perceptual, float(perceptual_weight)
         if perceptual is None and self.perceptual_weight != 0.0:
@@ -381,9 +386,17 @@ class VAETrainer:
             p_loss = None
             if self.perceptual is not None and self.perceptual_weight != 0.0:
                 p_loss = self._perceptual_term(recon, images, d_recon, p_target)
-            adv_ctx = None
+            adv_ctx = adv_disc = adv_done = None
             if adversarial:           # + adv_weight * generator term: its gradient w.r.t. the reconstruction joins d_recon
                 adv_gen, adv_ctx = self._adv_generator_term(recon, d_recon)
+                if self._adv_stream is not None:     # the discriminator's step, on its stream, under the VAE backward
+                    main = torch.cuda.current_stream()
+                    self._adv_stream.wait_stream(main)
+                    with torch.cuda.stream(self._adv_stream):
+                        adv_disc = self._adv_discriminator_losses(adv_ctx, images, train=True)
+                        adv_done = torch.cuda.Event()
+                        adv_done.record(self._adv_stream)
+                    adv_disc.record_stream(main)
             dz = eng.decode_backward(c_dec, d_recon, want_dz=True, join=False)   # encode_backward joins the side stream
             # z = mu + eps*sigma ; third = sigma (or 2 log sigma)
             d_sigma = d_third if net.third_output == "sigma" else d_third * (2.0 / sigma)
@@ -394,7 +407,11 @@ class VAETrainer:
         finally:
             eng.grad_ready_cb = None
         self.opt.step(grad_scale=1.0 / self.world)
-        adv_disc = self._adv_discriminator_losses(adv_ctx, images, train=True) if adversarial else None
+        if adversarial:
+            if adv_done is not None:
+                torch.cuda.current_stream().wait_event(adv_done)   # its loss and the updated discriminator, before returning
+            else:
+                adv_disc = self._adv_discriminator_losses(adv_ctx, images, train=True)
         done = torch.cuda.Event()
         done.record()
         self._step_done.append(done)

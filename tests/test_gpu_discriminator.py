@@ -529,3 +529,25 @@ def test_engine_vs_frozen_golden_vectors(dev):
     for n, _ in net.named_parameters():
         want = float(gold["gnorm_" + n.replace(".", "_")])
         assert float(net.grad_view(n).norm()) == pytest.approx(want, rel=6e-2), n   # kink-limited, see _pin_forward_state
+
+
+def test_discriminator_step_on_its_own_stream_is_bit_identical(dev):
+    """The discriminator's step runs on its own stream beside the VAE backward (default) -- generator and discriminator
+    parameters after three adversarial steps must equal, bit for bit, those of the serial schedule
+    (``_adv_stream = None`` = PTI_ADV_STREAM=0), and the returned loss must be readable right after ``step``."""
+    import dp_gpu_worker as W
+    from pti_ldm_vae_amd.trainer import VAETrainer
+    x, eps = W.fixed_inputs()
+    x, eps = x.to(dev), eps.to(dev)
+    res = []
+    for own_stream in (True, False):
+        model, disc = W.build_model(dev), W.build_disc(dev)
+        tr = VAETrainer(model, lr=W.LR, discriminator=disc, adv_weight=0.1)
+        assert tr._adv_stream is not None
+        if not own_stream:
+            tr._adv_stream = None
+        losses = [float(tr.step(x, eps, adversarial=True)["adv_disc"]) for _ in range(3)]
+        torch.cuda.synchronize()
+        res.append((losses, model.autoencoder.param_arena.detach().clone(), disc.param_arena.detach().clone()))
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
