@@ -209,15 +209,16 @@ class VAETrainer:
         return per.sum(), per, cnt
 
     # ---- adversarial branch -----------------------------------------------------------------------------------------
-    def _adv_generator_term(self, recon, d_recon):
+    def _adv_generator_term(self, recon, d_recon, accumulate=True):
         """train_vae.py:399-401: adv_loss(discriminator(recon)[-1], target_is_real=True, for_discriminator=False); adds
-        adv_weight * its gradient into ``d_recon`` (when given).  Returns (loss, the pass's context)."""
+        adv_weight * its gradient into ``d_recon`` (when given; ``accumulate=False``: writes it there instead).
+        Returns (loss, the pass's context)."""
         eng = self.disc_eng
         ctx = eng.forward(recon, save=d_recon is not None)
         loss, d = eng.lsgan(ctx, target_is_real=True, weight=self.adv_weight, want_grad=d_recon is not None,
                             slope=self.adv_slope)
         if d_recon is not None:
-            eng.backward(ctx, d, want_wgrad=False, d_img=d_recon, accumulate_dx=True)
+            eng.backward(ctx, d, want_wgrad=False, d_img=d_recon, accumulate_dx=accumulate)
         return loss, ctx
 
     def _adv_discriminator_losses(self, fake_ctx, images, train: bool):
@@ -384,19 +385,40 @@ class VAETrainer:
             if self.ar is not None:   # + gamma * AR-VAE(z_mu.mean(h, w)): its gradient goes straight into d_mu
                 ar_out = self._ar_term(mu, attributes, d_mu)
             p_loss = None
-            if self.perceptual is not None and self.perceptual_weight != 0.0:
-                p_loss = self._perceptual_term(recon, images, d_recon, p_target)
+            with_p = self.perceptual is not None and self.perceptual_weight != 0.0
             adv_ctx = adv_disc = adv_done = None
-            if adversarial:           # + adv_weight * generator term: its gradient w.r.t. the reconstruction joins d_recon
-                adv_gen, adv_ctx = self._adv_generator_term(recon, d_recon)
-                if self._adv_stream is not None:     # the discriminator's step, on its stream, under the VAE backward
-                    main = torch.cuda.current_stream()
-                    self._adv_stream.wait_stream(main)
-                    with torch.cuda.stream(self._adv_stream):
-                        adv_disc = self._adv_discriminator_losses(adv_ctx, images, train=True)
-                        adv_done = torch.cuda.Event()
-                        adv_done.record(self._adv_stream)
-                    adv_disc.record_stream(main)
+            if adversarial and with_p and self._adv_stream is not None:
+                # both optional terms depend on the reconstruction only: the generator's adversarial term runs on the
+                # discriminator's stream (followed there by the discriminator's own step) while the perceptual term
+                # runs here; the gradients join in the serial schedule's order, (VAE + perceptual) + adversarial
+                main, advs = torch.cuda.current_stream(), self._adv_stream
+                advs.wait_stream(main)
+                with torch.cuda.stream(advs):
+                    d_adv = torch.empty_like(d_recon)
+                    adv_gen, adv_ctx = self._adv_generator_term(recon, d_adv, accumulate=False)
+                    g_done = torch.cuda.Event()
+                    g_done.record(advs)
+                    adv_disc = self._adv_discriminator_losses(adv_ctx, images, train=True)
+                    adv_done = torch.cuda.Event()
+                    adv_done.record(advs)
+                for t in (d_adv, adv_gen, adv_disc):
+                    t.record_stream(main)
+                p_loss = self._perceptual_term(recon, images, d_recon, p_target)
+                main.wait_event(g_done)
+                d_recon.add_(d_adv)
+            else:
+                if with_p:
+                    p_loss = self._perceptual_term(recon, images, d_recon, p_target)
+                if adversarial:       # + adv_weight * generator term: its gradient w.r.t. the reconstruction joins d_recon
+                    adv_gen, adv_ctx = self._adv_generator_term(recon, d_recon)
+                    if self._adv_stream is not None:     # the discriminator's step, on its stream, under the VAE backward
+                        main = torch.cuda.current_stream()
+                        self._adv_stream.wait_stream(main)
+                        with torch.cuda.stream(self._adv_stream):
+                            adv_disc = self._adv_discriminator_losses(adv_ctx, images, train=True)
+                            adv_done = torch.cuda.Event()
+                            adv_done.record(self._adv_stream)
+                        adv_disc.record_stream(main)
             dz = eng.decode_backward(c_dec, d_recon, want_dz=True, join=False)   # encode_backward joins the side stream
             # z = mu + eps*sigma ; third = sigma (or 2 log sigma)
             d_sigma = d_third if net.third_output == "sigma" else d_third * (2.0 / sigma)

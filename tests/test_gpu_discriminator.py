@@ -551,3 +551,35 @@ def test_discriminator_step_on_its_own_stream_is_bit_identical(dev):
         res.append((losses, model.autoencoder.param_arena.detach().clone(), disc.param_arena.detach().clone()))
     assert res[0][0] == res[1][0]
     assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+
+
+def test_full_objective_step_concurrent_terms_vs_serial_schedule(dev):
+    """Perceptual + adversarial in one step: the generator's adversarial term (and then the discriminator's step) run on
+    the discriminator's stream while the perceptual term runs on the main stream.  Against the serial schedule
+    (``_adv_stream = None``): the adversarial gradient joins d_recon through one extra fp32 rounding (buffer + add
+    instead of an accumulating store), so the parameters agree to ~1e-6 relative after two steps, not bit for bit;
+    run to run the concurrent schedule IS bit-identical."""
+    import dp_gpu_worker as W
+    from pti_ldm_vae_amd.models import PerceptualLoss
+    from pti_ldm_vae_amd.trainer import VAETrainer
+    x, eps = W.fixed_inputs()
+    x, eps = x.to(dev), eps.to(dev)
+    torch.manual_seed(21)
+    ploss = PerceptualLoss(allow_random_init=True).to(dev)
+    res = []
+    for mode in ("concurrent", "concurrent", "serial"):
+        model, disc = W.build_model(dev), W.build_disc(dev)
+        tr = VAETrainer(model, lr=W.LR, discriminator=disc, adv_weight=0.1, perceptual=ploss, perceptual_weight=1.0)
+        if mode == "serial":
+            tr._adv_stream = None
+        for _ in range(2):
+            out = tr.step(x, eps, adversarial=True)
+        vals = [float(out[k]) for k in ("loss", "perceptual", "adv_gen", "adv_disc")]
+        torch.cuda.synchronize()
+        res.append((vals, model.autoencoder.param_arena.detach().clone(), disc.param_arena.detach().clone()))
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    for a, b in zip(res[0][0], res[2][0]):
+        assert a == pytest.approx(b, rel=1e-4)
+    # Adam's first steps move every parameter by ~lr whatever the gradient's size: compare against that scale
+    assert (res[0][1] - res[2][1]).abs().max().item() <= 0.05 * W.LR
+    assert (res[0][2] - res[2][2]).abs().max().item() <= 0.05 * W.LR
