@@ -81,3 +81,39 @@ def test_trainer_argument_validation():
     import inspect
     sig = inspect.signature(trainer.VAETrainer.__init__)
     assert "perceptual" in sig.parameters and "perceptual_weight" in sig.parameters
+
+
+def test_folded_first_layer_algebra_on_cpu():
+    """``perceptual_engine.fold_first_layer``: conv(3 -> 64, 3x3, stride 2, no padding) on the three scaled copies of a
+    one-channel image == a 1 -> 64 convolution with the folded weights / bias (exact algebra: the layer has no padding).
+    This is the operand of the HIP first-layer kernels; checked here against the torch layers in float64."""
+    import torch
+    import torch.nn.functional as F
+    from pti_ldm_vae_amd.models.perceptual import SqueezeLPIPS
+    from pti_ldm_vae_amd.perceptual_engine import fold_first_layer
+    from pti_ldm_vae_amd.utils.losses import ensure_three_channels
+    torch.manual_seed(0)
+    net = SqueezeLPIPS().double()
+    x = torch.rand(2, 1, 21, 18, dtype=torch.float64)
+    want = net.features[0]((ensure_three_channels(x) - net.shift) / net.scale)
+    w10 = fold_first_layer(net).double()                                  # [10, 64]: 9 taps (row-major) + bias
+    got = F.conv2d(x, w10[:9].t().reshape(64, 1, 3, 3), w10[9], stride=2)
+    assert got.shape == want.shape
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-6)                # w10 is stored in fp32
+
+
+def test_trunk_plan_matches_the_lpips_slices():
+    """The HIP trunk's plan (pools, Fire modules, which outputs are taps) against ``SqueezeLPIPS.SLICES`` / the layer
+    list of ``squeezenet1_1_features()``."""
+    from pti_ldm_vae_amd.models.perceptual import Fire, SqueezeLPIPS, _Pool, squeezenet1_1_features
+    from pti_ldm_vae_amd.perceptual_engine import _PLAN
+    feats = squeezenet1_1_features()
+    idx = 2                                                               # the trunk starts after conv + ReLU
+    tap_ends = {b - 1 for _, b in SqueezeLPIPS.SLICES}                    # feature index whose output is a tap
+    for st in _PLAN:
+        if st[0] == "pool":
+            assert isinstance(feats[idx], _Pool)
+        else:
+            assert isinstance(feats[idx], Fire) and st[1] == idx and st[2] == (idx in tap_ends)
+        idx += 1
+    assert idx == len(feats) and 1 in tap_ends
