@@ -386,6 +386,11 @@ def gn_bwd(x, da, dx, stats, gamma, beta, sums, dgamma, dbeta, *, groups, eps=1e
     return dx
 
 
+# Timing diagnostic ONLY (results are wrong: the GroupNorm-backward sums stay uninitialised): skips the finalize launch
+# between the data-gradient conv and gn_bwd_apply, to measure what that launch costs on the main stream's critical path.
+_DIAG_SKIP_FINALIZE = os.environ.get("PTI_DIAG_SKIP_FINALIZE") == "1"
+
+
 def conv_mfma_gnbwd(dy_in, w_packed_t, gx, gstats, ggamma, gbeta, dy_out, gsums, *, cout, ksize=3, mode=PTI_CONV_S1,
                     groups=0, eps=1e-6, silu=True):
     """Data-gradient conv with the GroupNorm(+SiLU) backward reduction fused into its epilogue:
@@ -417,7 +422,8 @@ def conv_mfma_gnbwd(dy_in, w_packed_t, gx, gstats, ggamma, gbeta, dy_out, gsums,
     if prof is not None:
         e1.record()
         name = last_kernel_name()
-    L.check(L.lib().pti_gn_sums_finalize(_ptr(part), _ptr(gsums), n, tiles, 2 * cout, _stream()), "pti_gn_sums_finalize")
+    if not _DIAG_SKIP_FINALIZE:
+        L.check(L.lib().pti_gn_sums_finalize(_ptr(part), _ptr(gsums), n, tiles, 2 * cout, _stream()), "pti_gn_sums_finalize")
     if prof is not None:
         prof.append((name, 2.0 * n * ho * wo * cout * cin * ksize * ksize * (0.25 if mode == PTI_CONV_ZINS else 1.0),
                      2.0 * (dy_in.numel() + 2 * dy_out.numel()), e0, e1,
