@@ -389,6 +389,9 @@ def gn_bwd(x, da, dx, stats, gamma, beta, sums, dgamma, dbeta, *, groups, eps=1e
 # Timing diagnostic ONLY (results are wrong: the GroupNorm-backward sums stay uninitialised): skips the finalize launch
 # between the data-gradient conv and gn_bwd_apply, to measure what that launch costs on the main stream's critical path.
 _DIAG_SKIP_FINALIZE = os.environ.get("PTI_DIAG_SKIP_FINALIZE") == "1"
+# The same for gn_bwd_apply itself ("1": skip the launch, dx keeps the buffer's old contents; "zero": a memset instead):
+# an upper bound on what fusing it into the neighbouring convolutions could save.
+_DIAG_SKIP_GNB_APPLY = os.environ.get("PTI_DIAG_SKIP_GNB_APPLY", "")
 
 
 def conv_mfma_gnbwd(dy_in, w_packed_t, gx, gstats, ggamma, gbeta, dy_out, gsums, *, cout, ksize=3, mode=PTI_CONV_S1,
@@ -443,6 +446,9 @@ def gn_bwd_apply(x, dy, dx, stats, gamma, beta, sums, dgamma, dbeta, *, groups, 
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+    if _DIAG_SKIP_GNB_APPLY:       # timing diagnostic only: dx stays whatever the buffer held (zeroed so that nothing overflows)
+        dx.zero_() if _DIAG_SKIP_GNB_APPLY == "zero" else None
+        return dx
     L.check(L.lib().pti_gn_bwd_apply(_ptr(x), _ptr(dy), _ptr(dres), _ptr(dx), _ptr(stats), _ptr(gamma), _ptr(beta),
                                      _ptr(sums), _ptr(dgamma), _ptr(dbeta), n, h * w, c, groups, eps,
                                      int(x.dtype == F16), _stream()), "pti_gn_bwd_apply")
