@@ -446,8 +446,9 @@ def gn_bwd_apply(x, dy, dx, stats, gamma, beta, sums, dgamma, dbeta, *, groups, 
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    if _DIAG_SKIP_GNB_APPLY:       # timing diagnostic only: dx stays whatever the buffer held (zeroed so that nothing overflows)
-        dx.zero_() if _DIAG_SKIP_GNB_APPLY == "zero" else None
+    if _DIAG_SKIP_GNB_APPLY:       # timing diagnostic only (results are wrong)
+        if _DIAG_SKIP_GNB_APPLY == "zero":
+            dx.zero_()
         return dx
     L.check(L.lib().pti_gn_bwd_apply(_ptr(x), _ptr(dy), _ptr(dres), _ptr(dx), _ptr(stats), _ptr(gamma), _ptr(beta),
                                      _ptr(sums), _ptr(dgamma), _ptr(dbeta), n, h * w, c, groups, eps,
