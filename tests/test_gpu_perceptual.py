@@ -395,3 +395,33 @@ def test_train_script_with_local_perceptual_weight_files(dev, tmp_path):
         torch.cuda.synchronize()
         outs.append((out["perceptual"].item(), m.autoencoder.param_arena.detach().clone()))
     assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_trunk_entry_points_refuse_bad_arguments(dev):
+    """Shapes the kernels do not cover are refused on the host, before any launch (the library never faults on them)."""
+    from pti_ldm_vae_amd import ops
+    from pti_ldm_vae_amd.models.perceptual import SqueezeLPIPS
+    x12 = torch.zeros(1, 4, 4, 12, device=dev).half()                     # channels not a multiple of 8
+    with pytest.raises(RuntimeError):
+        ops.maxpool3s2_fwd(x12)
+    with pytest.raises((ValueError, TypeError)):
+        ops.maxpool3s2_fwd(torch.zeros(1, 4, 4, 16, device=dev))          # fp32 instead of fp16
+    x = torch.zeros(1, 5, 5, 16, device=dev).half()
+    y = ops.maxpool3s2_fwd(x)
+    with pytest.raises((ValueError, TypeError)):
+        ops.maxpool3s2_bwd(torch.zeros(1, 3, 3, 16, device=dev).bfloat16(), x, y)      # gy of the wrong size
+    with pytest.raises((ValueError, TypeError)):
+        ops.relu_bwd_(torch.zeros(8, device=dev).bfloat16(), torch.zeros(16, device=dev).half())
+    with pytest.raises((ValueError, TypeError)):
+        ops.squeeze_conv1_fwd(torch.zeros(1, 3, 8, 8, device=dev), torch.zeros(10, 64, device=dev))   # three channels
+    with pytest.raises(RuntimeError):
+        ops.squeeze_conv1_fwd(torch.zeros(1, 1, 2, 8, device=dev), torch.zeros(10, 64, device=dev))   # smaller than the kernel
+    with pytest.raises((ValueError, TypeError)):
+        ops.lpips_tap_nhwc_fwd(torch.zeros(1, 2, 2, 40, device=dev).half(), torch.zeros(1, 2, 2, 40, device=dev).half(),
+                               torch.zeros(40, device=dev))               # 40 channels: no lane layout
+    # the trunk itself refuses anything but a contiguous NHWC fp16 map with the first layer's width
+    tr = SqueezeLPIPS().to(dev).trunk()
+    with pytest.raises(ValueError):
+        tr.forward(torch.zeros(1, 9, 9, 32, device=dev).half(), save=False)
+    with pytest.raises(ValueError):
+        tr.forward(torch.zeros(1, 64, 9, 9, device=dev).half().permute(0, 2, 3, 1), save=False)
