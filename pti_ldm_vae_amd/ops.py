@@ -177,6 +177,9 @@ def conv_mfma(x, w_packed, bias, y, *, cout, ksize=3, mode=PTI_CONV_S1, prologue
 # table; None costs nothing.  The kernel name is the symbol the HIP runtime reports for the launch
 # (pti_last_kernel_name), shortened the way tools/pmc_traffic.py shortens rocprofv3's Kernel_Name column.
 KERNEL_PROFILE = None
+# Timing diagnostic ONLY: drop every weight-gradient launch (what the side stream carries) to see how long the main
+# stream's work takes when it has the GPU to itself.  Results are wrong.
+_DIAG_SKIP_WGRAD = os.environ.get("PTI_DIAG_SKIP_WGRAD") == "1"
 
 
 def last_kernel_name() -> str:
@@ -233,6 +236,8 @@ def wgrad_direct(wide, narrow, dw, *, n, h, w, cw, cn, ksize, sgn, narrow_layout
                  workspace=None):
     """dw[tap,cw,k] += sum_p narrow[p,k] * T(wide)[p + sgn*tap, cw]; dw_strides = (tap, cw, k) element
     strides into the fp32 OIHW gradient ``dw`` (must be zero-initialised or hold a running sum)."""
+    if _DIAG_SKIP_WGRAD:       # timing diagnostic only (no weight gradients: results are wrong)
+        return dw
     _chk(wide, ACT16, "wide", 4)
     _chk(dw, F32, "dw")
     if prologue != PTI_PRO_NONE:
@@ -262,6 +267,8 @@ def wgrad_workspace(device, nbytes=48 << 20):
 
 def conv_wgrad_mfma(x, dy, dw, dbias, *, ksize=3, mode=PTI_CONV_S1, prologue=PTI_PRO_NONE, in_stats=None, gamma=None,
                     beta=None, groups=0, eps=1e-6, accumulate=False, workspace=None):
+    if _DIAG_SKIP_WGRAD:       # timing diagnostic only (no weight gradients: results are wrong)
+        return dw
     _chk(x, ACT16, "x", 4)
     _chk(dy, BF16, "dy", 4)
     _chk(dw, F32, "dw")
@@ -318,6 +325,8 @@ def wgrad_batch_eligible(x, dy, ksize, mode, prologue):
 def conv_wgrad_mfma_batched(jobs, workspace=None, accumulate=True):
     """``jobs``: up to WGRAD_BATCH_MAX tuples (x [n,h,w,cin] bf16, dy [n,h,w,cout] bf16, dw fp32 [cout*cin*9], dbias fp32
     [cout] | None) of plain stride-1 3x3 convs -> ONE partial launch + ONE reduction launch on the current stream."""
+    if _DIAG_SKIP_WGRAD:       # timing diagnostic only (no weight gradients: results are wrong)
+        return None
     if not 1 <= len(jobs) <= L.WGRAD_BATCH_MAX:
         raise ValueError(f"conv_wgrad_mfma_batched: 1..{L.WGRAD_BATCH_MAX} jobs, got {len(jobs)}")
     arr = (L.WgradJob * len(jobs))()
