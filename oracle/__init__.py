@@ -10,5 +10,7 @@ this image, and the reference has no tests: **parity unpinned** for the
 encoder/decoder (restated from SURVEY.md Appendix A).  The loss functions
 (``src/pti_ldm_vae/models/losses.py``) ARE pinned: ``oracle/make_golden.py``
 imports that file by path in the build container and commits its outputs as
-fixtures under ``tests/golden/``.
+fixtures under ``tests/golden/``.  ``oracle/perceptual.py`` (LPIPS / SqueezeNet-1.1 term, the checker of the
+perceptual tests since round 3) and ``oracle/patch_discriminator.py`` are **parity unpinned** for the same reason
+as the encoder/decoder (lpips / torchvision / MONAI absent, no weights, no reference output).
 """

@@ -11,6 +11,20 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PTI_VAE_LIB") or os.path.join(_HERE, "libpti_vae_hip.so")   # env: kernel-variant A/B runs
 
+def env_overrides() -> dict:
+    """Every ``PTI_*`` environment variable that is set (tuning / A-B knobs): recorded by bench.py in its JSON line."""
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("PTI_")}
+
+
+def refuse_wrong_result_env(who: str) -> None:
+    """Measurement and training entry points call this first: a variable that makes kernels skip work or produce
+    garbage (``PTI_*DIAG*``, ``PTI_ALLOW_WRONG_RESULTS``) must never reach a timed region or a training run."""
+    bad = [k for k in os.environ if k.startswith("PTI_") and ("DIAG" in k or k == "PTI_ALLOW_WRONG_RESULTS")]
+    if bad:
+        raise SystemExit(f"{who}: refusing to run with wrong-result diagnostic variable(s) set: {sorted(bad)} "
+                         "(timing diagnostics live in tools/diag_skip.py)")
+
+
 ABI_VERSION = 4   # PTI_ABI_VERSION of include/pti_vae.h
 PTI_CONV_S1, PTI_CONV_S2PAD, PTI_CONV_UP2, PTI_CONV_ZINS = 0, 1, 2, 3
 PTI_PRO_NONE, PTI_PRO_GN, PTI_PRO_GN_SILU = 0, 1, 2

@@ -983,6 +983,19 @@ static bool w4_eligible(int n, int h, int w, int cin, int cout) {
   return n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && cin % 32 == 0 && cout % 32 == 0 &&
          (long long)n * h * w * cin * 2 < (1ll << 31) && (long long)n * h * w * cout * 2 < (1ll << 31);
 }
+// Tuning aid that yields GARBAGE results (see WgArgs::diag): honoured only together with the explicit second opt-in
+// PTI_ALLOW_WRONG_RESULTS=1, and announced on stderr; bench.py / train_vae.py refuse to run with either variable set.
+static int wgrad_diag_env() {
+  const char* v = getenv("PTI_WGRAD_V4_DIAG");
+  const char* ok = getenv("PTI_ALLOW_WRONG_RESULTS");
+  if (!v || atoi(v) == 0) return 0;
+  if (!ok || atoi(ok) != 1) {
+    fprintf(stderr, "[pti] PTI_WGRAD_V4_DIAG ignored: it needs PTI_ALLOW_WRONG_RESULTS=1 (results are garbage)\n");
+    return 0;
+  }
+  fprintf(stderr, "[pti] WRONG-RESULT DIAGNOSTIC ACTIVE: PTI_WGRAD_V4_DIAG=%s\n", v);
+  return atoi(v);
+}
 // Pixel splits per job so that every workgroup of the launch streams about the same number of tiles and the launch has
 // about `wgs` workgroups; slab carving; reduction-block ranges; the XCD group lists.  One workgroup is resident per
 // CU (it owns the whole LDS); ~2048 workgroups (planned; the 256-group cap usually binds first) measured best inside the training step, where the launch
@@ -991,7 +1004,7 @@ static bool w4_eligible(int n, int h, int w, int cin, int cout) {
 // Returns the floats of workspace used, or -1 if it does not fit.
 static long long w4_plan(W4Batch& b, float* workspace, long long workspace_floats) {
   static const int wgs_env = getenv("PTI_WGRAD_V4_WGS") ? atoi(getenv("PTI_WGRAD_V4_WGS")) : 2048;
-  static const int diag_env = getenv("PTI_WGRAD_V4_DIAG") ? atoi(getenv("PTI_WGRAD_V4_DIAG")) : 0;
+  static const int diag_env = wgrad_diag_env();
   b.diag = diag_env;
   // workgroups of one pixel split: (co, ci) blocks of 32 x 32, or of 64 x 32 in the two-block mode
   auto tiles32 = [](const W4Job& a) { return (a.Cin / 32) * (a.Cout / (a.cob2 ? 64 : 32)); };
@@ -1078,7 +1091,7 @@ extern "C" int pti_conv_wgrad_mfma_partials(const void* x, const void* dy, const
   a.slab = (float*)workspace;
   a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Ho = d->ho; a.Wo = d->wo; a.Cout = d->cout;
   a.mode = d->mode; a.prologue = d->prologue; a.groups = d->groups; a.eps = d->eps; a.x_f16 = d->in_f16;
-  static const int diag_env = getenv("PTI_WGRAD_V4_DIAG") ? atoi(getenv("PTI_WGRAD_V4_DIAG")) : 0;
+  static const int diag_env = wgrad_diag_env();
   a.diag = diag_env;
   a.inv_cnt = d->prologue != PTI_PRO_NONE ? 1.0f / ((float)(d->cin / d->groups) * (float)d->h * (float)d->w) : 0.f;
   a.tiles_x = cdiv(d->wo, TW); a.tiles_y = cdiv(d->ho, TH); a.ntiles = d->n * a.tiles_x * a.tiles_y;

@@ -296,10 +296,16 @@ class _DirectConv:
         self.pack_f16 = False
 
     def repack(self):
+        """Derived operands are written IN PLACE into buffers allocated once: captured HIP graphs (inference encode /
+        decode, the training step) hold these addresses, so a re-pack must never move them (fresh tensors
+        per re-pack left replayed graphs reading freed memory after a native optimiser step)."""
         w = self.w.data
-        self.w_tck = w.permute(2, 3, 1, 0).reshape(9, self.cin, self.cout).contiguous()
+        if self.w_tck is None:
+            self.w_tck = torch.empty(9, self.cin, self.cout, dtype=F32, device=w.device)
+            self.w_tck_t = torch.empty(9, self.cout, self.cin, dtype=F32, device=w.device)
+        self.w_tck.view(3, 3, self.cin, self.cout).copy_(w.permute(2, 3, 1, 0))
         # data-gradient operand: w'[tap'][co][ci] = w[co][ci][8 - tap']
-        self.w_tck_t = w.flip(2, 3).permute(2, 3, 0, 1).reshape(9, self.cout, self.cin).contiguous()
+        self.w_tck_t.view(3, 3, self.cout, self.cin).copy_(w.flip(2, 3).permute(2, 3, 0, 1))
         if self.mfma_narrow:
             if self.wpad is None:   # narrow channels padded to 32: [32, wide, 3, 3] (conv_out) or [wide, 32, 3, 3] (conv_in)
                 shape = (32, self.cin, 3, 3) if self.cout < self.cin else (self.cout, 32, 3, 3)
@@ -338,6 +344,7 @@ class Engine:
         self.dev = net.param_arena.device
         self.workspace = ops.wgrad_workspace(self.dev)
         self.packed_version = -1
+        self.pack_gen = 0            # number of re-packs so far (monotonic; tests and diagnostics)
         self.grad_ready_cb = None
         self._range_cache = {}
         self._zpool, self._zoff, self._zpool_size = None, 0, 1 << 16
@@ -433,6 +440,24 @@ class Engine:
         self._zpool_size = (64 * batch * cmax * 2) if backward else (96 * batch * self.G * 2)
         self._zpool = None
 
+    def _pack_buffer_ids(self):
+        """Addresses of every derived weight operand a captured inference graph reads."""
+        ids = [t.data_ptr() for c in self.mfma_convs for t in (c.wp, c.wpt) if t is not None]
+        for c in self.direct_convs:
+            ids += [t.data_ptr() for t in (c.w_tck, c.w_tck_t, c.wp_mfma, c.wpad) if t is not None]
+        return tuple(ids)
+
+    def _drop_stale_graphs(self):
+        """Inference graphs stay valid across re-packs because every pack writes in place (``pack_gen`` counts the
+        re-packs; the replays see the new contents at the old addresses).  They are dropped only if an operand buffer
+        was (re)allocated since the capture -- keyed on the buffers' addresses, not on the parameters' version sum,
+        which a native optimiser step leaves unchanged."""
+        ids = self._pack_buffer_ids()
+        if ids != self._enc_graph_version:
+            self._enc_graphs.clear()
+            self._dec_graphs.clear()
+            self._enc_graph_version = ids
+
     def refresh_weights(self):
         """Re-derive the bf16 MFMA-packed / transposed operands when the fp32 masters changed.  In-place
         updates through the nn.Parameters (torch optimisers, load_state_dict) bump the parameters' own
@@ -452,6 +477,7 @@ class Engine:
         for c in self.direct_convs:
             c.repack()
         self.packed_version = v
+        self.pack_gen += 1
 
     def _qp(self, name):
         L = self.Lc
@@ -744,10 +770,7 @@ class Engine:
             return None
         x = self._check_input(x, self.net.in_channels, "encode")
         self.refresh_weights()
-        if self._enc_graph_version != self.packed_version:
-            self._enc_graphs.clear()
-            self._dec_graphs.clear()
-            self._enc_graph_version = self.packed_version
+        self._drop_stale_graphs()
         key = tuple(x.shape)
         ent = self._enc_graphs.get(key)
         if ent is None:
@@ -793,10 +816,7 @@ class Engine:
             return None
         z = self._check_input(z, self.Lc, "decode")
         self.refresh_weights()
-        if self._enc_graph_version != self.packed_version:
-            self._enc_graphs.clear()
-            self._dec_graphs.clear()
-            self._enc_graph_version = self.packed_version
+        self._drop_stale_graphs()
         key = tuple(z.shape)
         ent = self._dec_graphs.get(key)
         if ent is None:

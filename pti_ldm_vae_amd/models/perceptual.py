@@ -6,15 +6,16 @@ batch) and ``:395-397`` applies it to ``ensure_three_channels(reconstruction)`` 
 weight 1.0 in every shipped config.
 
 Status here: the pretrained weights (torchvision ``squeezenet1_1`` + lpips ``squeeze.pth``) cannot be fetched — there is
-no network — and neither ``lpips`` nor ``torchvision`` is installed, so the network is RESTATED below in plain torch with
-the two packages' ``state_dict`` key names, and ``PerceptualLoss(weights=(backbone_file, lin_file))`` loads files the
-user supplies locally (``torch.load(..., weights_only=True)``).  The feature network runs as ordinary torch ops on the HIP
-device (a fixed extractor next to the hot path, 2 % of the parameters; its convolutions could not be checked against real
-weights here); the memory-bound comparison tail of every tap -- normalise both maps, squared difference, ``lin`` layer,
-spatial mean, and its backward -- is two hand-written HIP kernels on the device (``csrc/lpips.hip``,
-``pti_lpips_tap_fwd`` / ``_bwd``: 2.9 -> 0.4 ms of the term at batch 32), the torch formula below being what CPU tensors
-take (the tests' checker).  The gradient w.r.t. the reconstruction is taken by autograd and ADDED to the native step's
-``d_recon`` (``VAETrainer(perceptual=...)``), so the VAE itself still runs on the HIP engine.
+no network — and neither ``lpips`` nor ``torchvision`` is installed.  This module is the PARAMETER HOLDER (``torch.nn``
+modules only so that ``state_dict()`` carries the two packages' key names; ``PerceptualLoss(weights=(backbone_file,
+lin_file))`` loads files the user supplies locally with ``torch.load(..., weights_only=True)``) plus the autograd glue of
+the HIP path.  Like every other module of this package it is **HIP-only**: the arithmetic is ``perceptual_engine.py`` +
+``csrc/squeeze.hip`` / ``csrc/lpips.hip`` behind the C-ABI -- one-channel images (what the VAE produces) run entirely on
+the library (first layer folded to one input channel, Fire modules on the MFMA convs, pooling, comparison tail);
+three-channel inputs take ``torch``'s convolution for the first layer only (a device op, plumbing next to the hot path)
+and enter the trunk through the layout kernels.  CPU tensors are REFUSED; there is no torch formulation of the term in
+the product -- the checker lives in ``oracle/perceptual.py`` (test infrastructure).
+The gradient w.r.t. the reconstruction is ADDED to the native step's ``d_recon`` (``VAETrainer(perceptual=...)``).
 Parity: UNPINNED (restated from the published structure of both packages; no weights, no reference output available).
 Without supplied weights the class refuses to build unless ``allow_random_init=True`` (tests, throughput runs).
 """
@@ -39,13 +40,13 @@ class Fire(nn.Module):
         self.expand3x3 = nn.Conv2d(squeeze, e3, 3, padding=1)
 
     def forward(self, x):
-        x = F.relu(self.squeeze(x))
-        return torch.cat([F.relu(self.expand1x1(x)), F.relu(self.expand3x3(x))], 1)
+        raise NotImplementedError("parameter holder: a Fire module runs as perceptual_engine._Fire (two MFMA convolutions); "
+                                  "the torch restatement used as the tests' checker is oracle/perceptual.py")
 
 
 class _Pool(nn.Module):
     def forward(self, x):
-        return F.max_pool2d(x, 3, 2, ceil_mode=True)
+        raise NotImplementedError("parameter-free marker: the pooling runs as ops.maxpool3s2_fwd / _bwd")
 
 
 class _Relu(nn.Module):
@@ -71,25 +72,6 @@ class _Lin(nn.Module):
 
     def forward(self, x):
         return self.model(x)
-
-
-class _LpipsTapFn(torch.autograd.Function):
-    """One tap's comparison on the device: (a, b, w) -> value [N]; gradient to ``a`` only (``b`` is the target's map, ``w``
-    a frozen weight).  HIP kernels behind ``ops.lpips_tap_fwd`` / ``ops.lpips_tap_bwd``."""
-
-    @staticmethod
-    def forward(ctx, a, b, w):
-        from .. import ops
-        a, b, w = a.contiguous(), b.contiguous(), w.contiguous()
-        val, saved = ops.lpips_tap_fwd(a, b, w)
-        ctx.save_for_backward(a, b, w, saved)
-        return val
-
-    @staticmethod
-    def backward(ctx, g):
-        from .. import ops
-        a, b, w, saved = ctx.saved_tensors
-        return ops.lpips_tap_bwd(a, b, w, saved, g.contiguous().float()), None, None
 
 
 class _TrunkCompareFn(torch.autograd.Function):
@@ -157,21 +139,12 @@ class _OneChannelCompareFn(torch.autograd.Function):
         return dx, None, None, None
 
 
-def lpips_tap_torch(a, b, lin_weight):
-    """The tap comparison as torch ops (lpips' normalize_tensor, squared difference, lin layer, spatial mean) -> [N]."""
-    a = a / (a.pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
-    b = b / (b.pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
-    return F.conv2d((a - b) ** 2, lin_weight).mean((2, 3)).view(-1)
-
-
 class SqueezeLPIPS(nn.Module):
     """``lpips.LPIPS(net="squeeze", lpips=True, spatial=False)`` in eval mode: input scaling, seven SqueezeNet-1.1
     feature taps (``features[0:2], [2:5], [5:8], [8:10], [10:11], [11:12], [12:13]``), channel-unit-normalised squared
     differences weighted by the ``lin`` layers, spatially averaged and summed.  Returns [N,1,1,1]."""
 
     SLICES = ((0, 2), (2, 5), (5, 8), (8, 10), (10, 11), (11, 12), (12, 13))
-    fused_tail = True      # device tensors take the HIP tail kernels (False: torch ops everywhere; A/B and tests)
-    native_trunk = True    # device tensors take the HIP trunk after the first convolution (perceptual_engine.SqueezeTrunk)
     _trunk = None
 
     def __init__(self):
@@ -185,21 +158,14 @@ class SqueezeLPIPS(nn.Module):
             p.requires_grad_(False)
         self.eval()
 
-    def _taps(self, x):
-        out = []
-        for a, b in self.SLICES:
-            for i in range(a, b):
-                x = self.features[i](x)
-            out.append(x)
-        return out
-
-    def taps(self, x):
-        """Input scaling + the seven feature taps of a 3-channel image batch (torch ops)."""
-        return self._taps((x - self.shift) / self.scale)
-
-    # ---- device path: first layer in torch, everything after it on the HIP library -------------------------------------
-    def use_native(self, x) -> bool:
-        return bool(self.native_trunk and self.fused_tail and x.is_cuda and x.dtype == torch.float32)
+    # ---- the only path: the HIP library (CPU tensors are refused) ------------------------------------------------------
+    def require_device(self, x, what="input"):
+        if not (x.is_cuda and self.features[0].weight.is_cuda):
+            raise RuntimeError(f"pti_ldm_vae_amd PerceptualLoss runs on MI355X only ({what} / module on "
+                               f"{x.device} / {self.features[0].weight.device}): there is no CPU or torch fallback for the "
+                               "term -- the CPU restatement used as the tests' checker is oracle/perceptual.py")
+        if x.dtype != torch.float32 or x.dim() != 4:
+            raise TypeError(f"PerceptualLoss: expected fp32 [N,C,H,W], got {x.dtype} {tuple(x.shape)}")
 
     def trunk(self):
         dev = self.features[0].weight.device
@@ -209,19 +175,22 @@ class SqueezeLPIPS(nn.Module):
         return self._trunk
 
     def tap0(self, x):
+        """First layer of a THREE-channel batch: torch's convolution on the device (one-channel images never come here)."""
         x = (x - self.shift) / self.scale
         return self.features[1](self.features[0](x))
 
     @torch.no_grad()
     def native_target_taps(self, x):
-        """The seven taps of the TARGET as ``native_compare`` consumes them (tap 0 NCHW fp32 as the torch first layer
-        leaves it, taps 1..6 NHWC fp16 from the HIP trunk), no autograd graph."""
+        """The seven taps of a three-channel TARGET as ``native_compare`` consumes them (tap 0 NCHW fp32 as the first
+        layer leaves it, taps 1..6 NHWC fp16 from the HIP trunk), no autograd graph."""
         from .. import ops
+        self.require_device(x, "target")
         t0 = self.tap0(x).contiguous()
         taps, _ = self.trunk().forward(ops.nchw_f32_to_nhwc_f16(t0), save=False)
         return [t0] + taps
 
     def native_compare(self, in0, target_taps):
+        self.require_device(in0)
         lin_ws = [getattr(self, f"lin{k}").model[1].weight.view(-1) for k in range(len(self.SLICES))]
         return _TrunkCompareFn.apply(self.tap0(in0), self.trunk(), target_taps, lin_ws).view(-1, 1, 1, 1)
 
@@ -229,30 +198,20 @@ class SqueezeLPIPS(nn.Module):
     @torch.no_grad()
     def native_target_taps_1ch(self, x1):
         from .. import ops
+        self.require_device(x1, "target")
         tr = self.trunk()
         t0 = ops.squeeze_conv1_fwd(x1.contiguous(), tr.w10)
         taps, _ = tr.forward(t0, save=False)
         return [t0] + taps
 
     def native_compare_1ch(self, x1, target_taps):
+        self.require_device(x1)
         lin_ws = [getattr(self, f"lin{k}").model[1].weight.view(-1) for k in range(len(self.SLICES))]
         return _OneChannelCompareFn.apply(x1, self.trunk(), target_taps, lin_ws).view(-1, 1, 1, 1)
 
     def forward(self, in0, in1):
-        if self.use_native(in0):
-            return self.native_compare(in0, self.native_target_taps(in1))
-        return self.compare(self.taps(in0), self.taps(in1))
-
-    def compare(self, f0, f1):
-        """LPIPS from two sets of taps -> [N,1,1,1] (gradients flow to ``f0`` only through the device kernels)."""
-        total = 0.0
-        for k, (a, b) in enumerate(zip(f0, f1)):
-            w = getattr(self, f"lin{k}").model[1].weight
-            if a.is_cuda and a.dtype == torch.float32 and self.fused_tail:
-                total = total + _LpipsTapFn.apply(a, b, w.view(-1))
-            else:
-                total = total + lpips_tap_torch(a, b, w)
-        return total.view(-1, 1, 1, 1)
+        """LPIPS of two three-channel batches on the device -> [N,1,1,1]."""
+        return self.native_compare(in0, self.native_target_taps(in1))
 
     def load_state_dict(self, *args, **kwargs):
         self._trunk = None          # the HIP trunk packs the weights once: rebuild it from the loaded ones
@@ -297,28 +256,29 @@ class PerceptualLoss(nn.Module):
                                "(or allow_random_init=True for tests / throughput runs).")
         self.pretrained = weights is not None
 
-    def _one_channel_native(self, t: torch.Tensor) -> bool:
-        return t.dim() == 4 and t.shape[1] == 1 and self.net.use_native(t.float()) and min(t.shape[2:]) >= 3
+    @staticmethod
+    def _one_channel(t: torch.Tensor) -> bool:
+        return t.dim() == 4 and t.shape[1] == 1 and min(t.shape[2:]) >= 3
 
     def forward(self, input: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
-        if self._one_channel_native(input) and self._one_channel_native(target):
-            return self.from_taps(input, self.target_taps(target))
-        return self.net(ensure_three_channels(input.float()), ensure_three_channels(target.float())).mean()
+        if not (self._one_channel(input) and self._one_channel(target)):      # mixed channel counts: both as three
+            input, target = ensure_three_channels(input.float()), ensure_three_channels(target.float())
+        return self.from_taps(input, self.target_taps(target))
 
     @torch.no_grad()
     def target_taps(self, target: torch.Tensor):
         """The target's feature taps alone (no autograd graph): they do not depend on the reconstruction, so the trainer
         computes them on its side stream while the VAE forward runs, and hands them to ``from_taps``."""
-        if self._one_channel_native(target):
-            return self.net.native_target_taps_1ch(target.float())
-        x = ensure_three_channels(target.float())
-        return self.net.native_target_taps(x) if self.net.use_native(x) else self.net.taps(x)
+        target = target.float()
+        self.net.require_device(target, "target")
+        if self._one_channel(target):
+            return self.net.native_target_taps_1ch(target)
+        return self.net.native_target_taps(ensure_three_channels(target))
 
     def from_taps(self, input: torch.Tensor, target_taps) -> torch.Tensor:
         """``forward(input, target)`` with the target's taps precomputed by ``target_taps(target)``."""
-        if self._one_channel_native(input) and target_taps[0].dtype == torch.float16:
-            return self.net.native_compare_1ch(input.float(), target_taps).mean()
-        x = ensure_three_channels(input.float())
-        if self.net.use_native(x):
-            return self.net.native_compare(x, target_taps).mean()
-        return self.net.compare(self.net.taps(x), target_taps).mean()
+        input = input.float()
+        self.net.require_device(input)
+        if self._one_channel(input) and target_taps[0].dtype == torch.float16:
+            return self.net.native_compare_1ch(input, target_taps).mean()
+        return self.net.native_compare(ensure_three_channels(input), target_taps).mean()

@@ -177,9 +177,6 @@ def conv_mfma(x, w_packed, bias, y, *, cout, ksize=3, mode=PTI_CONV_S1, prologue
 # table; None costs nothing.  The kernel name is the symbol the HIP runtime reports for the launch
 # (pti_last_kernel_name), shortened the way tools/pmc_traffic.py shortens rocprofv3's Kernel_Name column.
 KERNEL_PROFILE = None
-# Timing diagnostic ONLY: drop every weight-gradient launch (what the side stream carries) to see how long the main
-# stream's work takes when it has the GPU to itself.  Results are wrong.
-_DIAG_SKIP_WGRAD = os.environ.get("PTI_DIAG_SKIP_WGRAD") == "1"
 
 
 def last_kernel_name() -> str:
@@ -236,8 +233,6 @@ def wgrad_direct(wide, narrow, dw, *, n, h, w, cw, cn, ksize, sgn, narrow_layout
                  workspace=None):
     """dw[tap,cw,k] += sum_p narrow[p,k] * T(wide)[p + sgn*tap, cw]; dw_strides = (tap, cw, k) element
     strides into the fp32 OIHW gradient ``dw`` (must be zero-initialised or hold a running sum)."""
-    if _DIAG_SKIP_WGRAD:       # timing diagnostic only (no weight gradients: results are wrong)
-        return dw
     _chk(wide, ACT16, "wide", 4)
     _chk(dw, F32, "dw")
     if prologue != PTI_PRO_NONE:
@@ -267,8 +262,6 @@ def wgrad_workspace(device, nbytes=48 << 20):
 
 def conv_wgrad_mfma(x, dy, dw, dbias, *, ksize=3, mode=PTI_CONV_S1, prologue=PTI_PRO_NONE, in_stats=None, gamma=None,
                     beta=None, groups=0, eps=1e-6, accumulate=False, workspace=None):
-    if _DIAG_SKIP_WGRAD:       # timing diagnostic only (no weight gradients: results are wrong)
-        return dw
     _chk(x, ACT16, "x", 4)
     _chk(dy, BF16, "dy", 4)
     _chk(dw, F32, "dw")
@@ -325,8 +318,6 @@ def wgrad_batch_eligible(x, dy, ksize, mode, prologue):
 def conv_wgrad_mfma_batched(jobs, workspace=None, accumulate=True):
     """``jobs``: up to WGRAD_BATCH_MAX tuples (x [n,h,w,cin] bf16, dy [n,h,w,cout] bf16, dw fp32 [cout*cin*9], dbias fp32
     [cout] | None) of plain stride-1 3x3 convs -> ONE partial launch + ONE reduction launch on the current stream."""
-    if _DIAG_SKIP_WGRAD:       # timing diagnostic only (no weight gradients: results are wrong)
-        return None
     if not 1 <= len(jobs) <= L.WGRAD_BATCH_MAX:
         raise ValueError(f"conv_wgrad_mfma_batched: 1..{L.WGRAD_BATCH_MAX} jobs, got {len(jobs)}")
     arr = (L.WgradJob * len(jobs))()
@@ -395,14 +386,6 @@ def gn_bwd(x, da, dx, stats, gamma, beta, sums, dgamma, dbeta, *, groups, eps=1e
     return dx
 
 
-# Timing diagnostic ONLY (results are wrong: the GroupNorm-backward sums stay uninitialised): skips the finalize launch
-# between the data-gradient conv and gn_bwd_apply, to measure what that launch costs on the main stream's critical path.
-_DIAG_SKIP_FINALIZE = os.environ.get("PTI_DIAG_SKIP_FINALIZE") == "1"
-# The same for gn_bwd_apply itself ("1": skip the launch, dx keeps the buffer's old contents; "zero": a memset instead):
-# an upper bound on what fusing it into the neighbouring convolutions could save.
-_DIAG_SKIP_GNB_APPLY = os.environ.get("PTI_DIAG_SKIP_GNB_APPLY", "")
-
-
 def conv_mfma_gnbwd(dy_in, w_packed_t, gx, gstats, ggamma, gbeta, dy_out, gsums, *, cout, ksize=3, mode=PTI_CONV_S1,
                     groups=0, eps=1e-6, silu=True):
     """Data-gradient conv with the GroupNorm(+SiLU) backward reduction fused into its epilogue:
@@ -434,8 +417,7 @@ def conv_mfma_gnbwd(dy_in, w_packed_t, gx, gstats, ggamma, gbeta, dy_out, gsums,
     if prof is not None:
         e1.record()
         name = last_kernel_name()
-    if not _DIAG_SKIP_FINALIZE:
-        L.check(L.lib().pti_gn_sums_finalize(_ptr(part), _ptr(gsums), n, tiles, 2 * cout, _stream()), "pti_gn_sums_finalize")
+    L.check(L.lib().pti_gn_sums_finalize(_ptr(part), _ptr(gsums), n, tiles, 2 * cout, _stream()), "pti_gn_sums_finalize")
     if prof is not None:
         prof.append((name, 2.0 * n * ho * wo * cout * cin * ksize * ksize * (0.25 if mode == PTI_CONV_ZINS else 1.0),
                      2.0 * (dy_in.numel() + 2 * dy_out.numel()), e0, e1,
@@ -455,10 +437,6 @@ def gn_bwd_apply(x, dy, dx, stats, gamma, beta, sums, dgamma, dbeta, *, groups, 
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    if _DIAG_SKIP_GNB_APPLY:       # timing diagnostic only (results are wrong)
-        if _DIAG_SKIP_GNB_APPLY == "zero":
-            dx.zero_()
-        return dx
     L.check(L.lib().pti_gn_bwd_apply(_ptr(x), _ptr(dy), _ptr(dres), _ptr(dx), _ptr(stats), _ptr(gamma), _ptr(beta),
                                      _ptr(sums), _ptr(dgamma), _ptr(dbeta), n, h * w, c, groups, eps,
                                      int(x.dtype == F16), _stream()), "pti_gn_bwd_apply")

@@ -211,6 +211,8 @@ def load_checkpoint(args, model, opt, device, disc=None, opt_d=None):
 
 
 def main(argv=None):
+    from . import _lib
+    _lib.refuse_wrong_result_env("train_vae.py")    # timing diagnostics that drop launches never reach a training run
     args = parse_args(argv)
     ddp, rank, world, device, dist = setup_environment(args)
     args = load_config(args)

@@ -319,6 +319,11 @@ class VAETrainer:
                                dtype=torch.float32, device=images.device)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
+            # the weight re-pack launches must be PART of the graph (every replay follows an optimiser step): if a
+            # no_grad forward (validation, eval_losses) ran just before this call the packs are clean and
+            # refresh_weights() would return early during capture -- every replay would then train on the weights as
+            # last packed eagerly.  Force the dirty state for the capture.
+            self.eng.packed_version = -1
             try:
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):   # loader threads may issue copies meanwhile
                     out2 = self._plain_fwd_bwd(gx, geps)

@@ -88,3 +88,28 @@ def test_tile_and_block_queries_need_no_gpu():
     assert lib.pti_conv_gnbwd_tiles(C.byref(d)) == 0                            # not a multiple of 32: unsupported
     assert lib.pti_gn_bwd_blocks(2, 64 * 64, 64) >= 1
     assert lib.pti_gn_bwd_blocks(2, 64 * 64, 1024) == 0                         # above the kernel's channel cap
+
+
+def test_entry_points_refuse_wrong_result_environment(monkeypatch):
+    """no ``PTI_DIAG_*`` knob lives in the product any more; what is left (a native tuning aid that
+    needs PTI_ALLOW_WRONG_RESULTS=1 as a second opt-in) makes bench.py and train_vae.py exit before touching the GPU."""
+    import subprocess
+    import sys
+    hits = subprocess.run(["grep", "-rn", "PTI_DIAG", os.path.join(ROOT, "pti_ldm_vae_amd"), "--include=*.py",
+                           "--include=*.hip", "--include=*.h", "--include=*.cpp"], capture_output=True, text=True).stdout
+    assert hits == "", hits
+    import bench
+    from pti_ldm_vae_amd import train_vae
+    for var in ("PTI_DIAG_SKIP_WGRAD", "PTI_WGRAD_V4_DIAG", "PTI_ALLOW_WRONG_RESULTS"):
+        monkeypatch.setenv(var, "1")
+        monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "1", "--warmup", "0", "--batch", "2", "--size", "64"])
+        with pytest.raises(SystemExit) as e:
+            bench.main()
+        assert var in str(e.value)
+        with pytest.raises(SystemExit) as e:
+            train_vae.main(["--synthetic"])
+        assert var in str(e.value)
+        monkeypatch.delenv(var)
+    from pti_ldm_vae_amd import _lib
+    monkeypatch.setenv("PTI_WGRAD_STREAM", "0")
+    assert _lib.env_overrides().get("PTI_WGRAD_STREAM") == "0"

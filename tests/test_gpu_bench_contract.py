@@ -1,8 +1,10 @@
 """The driver's bench.py contract, checked in-process on a tiny workload (64x64, batch 2): ONE JSON line with the agreed
 keys -- metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype /
 data / config{workload,...} -- plus ``roofline`` {bound, achieved, peak, unit, frac, traffic} for the dominant kernel
-and ``cpu_baseline`` {value, unit, cores, kind, sample}."""
+and ``cpu_baseline`` {value, unit, cores, kind, sample}.  The line must stay under 4 KB (the driver keeps ~8 KB of stdout:
+round 2's 32 KB line was truncated and could not be parsed); the per-shape tables go to a file."""
 import json
+import os
 import sys
 
 import pytest
@@ -10,39 +12,62 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _run(monkeypatch, capsys, extra):
+def _run(monkeypatch, capsys, extra, tmp_path=None, small=True):
     import bench
-    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "3", "--warmup", "1", "--batch", "2", "--size", "64"] + extra)
+    argv = ["bench.py", "--steps", "3", "--warmup", "1"] + (["--batch", "2", "--size", "64"] if small else [])
+    if tmp_path is not None:
+        argv += ["--detail-out", str(tmp_path / "detail.json")]
+    monkeypatch.setattr(sys, "argv", argv + extra)
     bench.main()
     lines = [l for l in capsys.readouterr().out.strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1, "exactly one JSON line on stdout"
+    assert len(lines[0]) < 4096, f"bench line is {len(lines[0])} bytes (must stay under 4 KB)"
     return json.loads(lines[0])
 
 
-def test_default_line_has_the_contract_keys(dev, monkeypatch, capsys):
-    d = _run(monkeypatch, capsys, ["--cpu-steps", "1"])
+def test_default_line_has_the_contract_keys(dev, monkeypatch, capsys, tmp_path):
+    d = _run(monkeypatch, capsys, ["--cpu-steps", "1"], tmp_path)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
-    assert d["metric"] == "vae_train_images_per_sec_256x256_bf16" and d["unit"] == "images/s"
+    assert d["metric"] == "vae_train_images_per_sec_256x256" and d["unit"] == "images/s"
+    assert d["dtype"].startswith("fp16 forward") and "bf16 backward" in d["dtype"]      # what actually ran by default
+    assert isinstance(d["env_overrides"], dict) and not any("DIAG" in k for k in d["env_overrides"])
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
     assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
     assert d["value"] > 0 and d["ms_per_step"] > 0
     r = d["roofline"]
-    for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "secondary"):
         assert k in r, k
+    assert "<" not in r["kernel"], "the roofline is keyed on the kernel FUNCTION, instantiations folded"
+    assert r["kernel"] == "conv_mfma2_kernel" and r["bound"] == "mfma"
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and 0 <= r["frac"] <= 1.0
     assert r["achieved"] == pytest.approx(r["frac"] * r["peak"], rel=1e-2, abs=1e-4 * r["peak"])   # frac is rounded to 4 places
     assert r["traffic"] is None          # the committed counter passes belong to the batch-32 256x256 workload, not this one
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "images/s" and "sample" in c
-    assert isinstance(d["per_shape"], list) and d["per_shape"]
+    assert "per_shape" not in d and "all_mfma_kernels" not in r
+    detail = json.load(open(tmp_path / "detail.json"))
+    assert detail["per_shape"] and detail["instantiations"]
 
 
-def test_adversarial_and_regression_lines(dev, monkeypatch, capsys):
-    import os
+def test_line_stays_under_4k_at_the_default_workload(dev, monkeypatch, capsys, tmp_path):
+    """The DEFAULT workload (config A, batch 32, 256x256: ~64 distinct (shape, kernel) rows) is the one the driver runs."""
+    d = _run(monkeypatch, capsys, ["--cpu-steps", "1"], tmp_path, small=False)
+    assert d["config"]["global_batch"] == 32 and "256x256x1" in d["config"]["workload"]
+    assert d["roofline"]["kernel"] == "conv_mfma2_kernel" and len(d["roofline"]["secondary"]) == 3
+    assert d["cpu_baseline"]["value"] > 0
+    assert len(json.load(open(tmp_path / "detail.json"))["per_shape"]) > 40
+
+
+def test_three_channel_variant(dev, monkeypatch, capsys, tmp_path):
+    d = _run(monkeypatch, capsys, ["--no-cpu-baseline", "--channels", "3"], tmp_path)
+    assert "64x64x3" in d["config"]["workload"] and d["value"] > 0
+
+
+def test_adversarial_and_regression_lines(dev, monkeypatch, capsys, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    d = _run(monkeypatch, capsys, ["--no-cpu-baseline", "--adv"])
+    d = _run(monkeypatch, capsys, ["--no-cpu-baseline", "--adv"], tmp_path)
     assert "LSGAN(PatchDiscriminator)" in d["config"]["workload"] and d["value"] > 0
-    d = _run(monkeypatch, capsys, ["--no-cpu-baseline", "--config", os.path.join(root, "config", "reg_edente_from_dente.json")])
-    assert d["metric"] == "vae_encoder_regression_images_per_sec_256x256_bf16" and d["value"] > 0
+    d = _run(monkeypatch, capsys, ["--no-cpu-baseline", "--config", os.path.join(root, "config", "reg_edente_from_dente.json")], tmp_path)
+    assert d["metric"] == "vae_encoder_regression_images_per_sec_256x256" and d["value"] > 0

@@ -456,8 +456,8 @@ def test_train_script_with_adversarial_branch(dev, tmp_path):
 
 # ---- the perceptual term in the native step ----------------------------------------------------------------
 def test_native_step_with_perceptual_term_vs_oracle(dev):
-    """``VAETrainer(perceptual=PerceptualLoss(...), perceptual_weight=w).step`` against the oracle VAE + the same torch
-    module on the CPU (random-initialised network with non-negative lin weights: the pretrained files cannot be fetched,
+    """``VAETrainer(perceptual=PerceptualLoss(...), perceptual_weight=w).step`` against the oracle VAE + the oracle
+    perceptual network (oracle/perceptual.py, same weights) on the CPU (random-initialised network with non-negative lin weights: the pretrained files cannot be fetched,
     so this checks the plumbing -- value, scaling, sign and that the gradient really reaches the HIP backward -- not
     LPIPS itself).  The weight is chosen so that the term carries about half of the generator gradient."""
     from oracle.autoencoderkl import CONFIG_A, build_oracle, synthetic_images
@@ -465,10 +465,12 @@ def test_native_step_with_perceptual_term_vs_oracle(dev):
     from pti_ldm_vae_amd.models import PerceptualLoss, VAEModel
     from pti_ldm_vae_amd.trainer import VAETrainer
     torch.manual_seed(5)
+    from oracle import perceptual as OP
     ploss = PerceptualLoss(allow_random_init=True)
     with torch.no_grad():
         for k in range(7):
             getattr(ploss.net, f"lin{k}").model[1].weight.abs_()
+    psd = OP.cpu_state(ploss.net)                        # the CPU checker: oracle/perceptual.py on the same weights
     oracle = build_oracle(CONFIG_A, 42)
     model = VAEModel.from_config(CONFIG_A)
     model.load_state_dict(oracle.state_dict())
@@ -477,7 +479,7 @@ def test_native_step_with_perceptual_term_vs_oracle(dev):
     lat = 64 // 2 ** (len(CONFIG_A["channels"]) - 1)
     eps = torch.randn(2, CONFIG_A["latent_channels"], lat, lat, generator=torch.Generator().manual_seed(10))
     loss_o, _, _, (recon_o, _, _) = train_step_losses(oracle, x, eps)
-    p_o = ploss(recon_o, x)
+    p_o = OP.perceptual_loss(psd, recon_o, x)
     params = list(oracle.parameters())
     g_plain = torch.cat([g.flatten() for g in torch.autograd.grad(loss_o, params, retain_graph=True)])
     g_p = torch.cat([g.flatten() for g in torch.autograd.grad(p_o, params, retain_graph=True)])

@@ -98,17 +98,19 @@ def test_golden_vectors_A64(dev):
     assert _rel(sig.cpu(), torch.from_numpy(g["sigma"])) <= 2e-2
 
 
-@pytest.mark.parametrize("tag", ["A", "AR"])
-def test_training_step_parity(dev, tag):
-    """forward + L1 + KL + backward through the drop-in autograd path vs the oracle's autograd."""
+@pytest.mark.parametrize("tag,size", [("A", 64), ("AR", 64), ("AR", 256)])
+def test_training_step_parity(dev, tag, size):
+    """forward + L1 + KL + backward through the drop-in autograd path vs the oracle's autograd.  ("AR", 256) is BASELINE
+    config 4's model at its full image size, batch 1: the WHOLE backward of the AR model (256-channel convs at 64^2,
+    attention at L = 4096 / C = 256) end to end, not only its kernels in isolation (VERDICT r2 missing #6)."""
     from oracle.autoencoderkl import CONFIG_A, CONFIG_AR
     from oracle.losses import train_step_losses
     from pti_ldm_vae_amd.models import compute_kl_loss
     cfg = CONFIG_A if tag == "A" else CONFIG_AR
-    torch.set_num_threads(8)
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
     oracle, model = _build(cfg, dev)
     batch = 2 if tag == "A" else 1
-    x, eps = _inputs(cfg, batch, 64)
+    x, eps = _inputs(cfg, batch, size)
     loss_o, rec_l_o, kl_o, _ = train_step_losses(oracle, x, eps)
     loss_o.backward()
     xd, epsd = x.to(dev), eps.to(dev)
@@ -118,7 +120,7 @@ def test_training_step_parity(dev, tag):
     loss = rec_l + 1e-3 * kl
     loss.backward()
     torch.cuda.synchronize()
-    print(f"[{tag}] loss {loss.item():.6f} vs {loss_o.item():.6f} | recon {rec_l.item():.6f} vs {rec_l_o.item():.6f} | "
+    print(f"[{tag}@{size}] loss {loss.item():.6f} vs {loss_o.item():.6f} | recon {rec_l.item():.6f} vs {rec_l_o.item():.6f} | "
           f"kl {kl.item():.4f} vs {kl_o.item():.4f}")
     assert loss.item() == pytest.approx(loss_o.item(), rel=1e-3)
     assert kl.item() == pytest.approx(kl_o.item(), rel=1e-3)
@@ -136,7 +138,7 @@ def test_training_step_parity(dev, tag):
                 worst = (cos, n)
     fg, fo = torch.cat(flat_g), torch.cat(flat_o)
     cos_all = _cos(fg, fo)
-    print(f"[{tag}] grad cosine (all) {cos_all:.5f}  norm ratio {(fg.norm() / fo.norm()).item():.4f}  worst tensor {worst}")
+    print(f"[{tag}@{size}] grad cosine (all) {cos_all:.5f}  norm ratio {(fg.norm() / fo.norm()).item():.4f}  worst tensor {worst}")
     assert cos_all >= 0.999
     assert worst[0] >= 0.995, worst
     assert abs((fg.norm() / fo.norm()).item() - 1.0) <= 1e-2
@@ -240,7 +242,9 @@ def test_full_size_batch_independence_and_finite(dev):
     for name, full, sub in (("recon", rec[idx], rec_s), ("mu", mu[idx], mu_s), ("sigma", sig[idx], sig_s)):
         rel = _rel(sub, full)
         print(f"[A@256 b32 vs b3] {name} relL2 {rel:.2e}")
-        assert rel <= 2e-3, (name, rel)
+        # bit-exact: no kernel may pick its tiling, split or summation order from the batch size (it measured 0.0; a
+        # relL2 gate of 2e-3 would have let a mildly batch-dependent kernel through -- VERDICT r2 weak #7)
+        assert torch.equal(sub, full), (name, rel)
     # and an empty batch is refused before any launch
     with pytest.raises((ValueError, RuntimeError)):
         model.autoencoder.encode(torch.zeros(0, 1, 256, 256, device=dev))

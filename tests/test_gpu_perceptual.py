@@ -1,12 +1,23 @@
 """GPU tests of the LPIPS comparison tail kernels (csrc/lpips.hip; reference: train_vae.py:299,:395-397 ->
 monai PerceptualLoss("squeeze") -> lpips normalize_tensor / squared difference / lin layer / spatial mean).
 
-The checker is the same formula as torch ops in float64 on the CPU (``lpips_tap_torch``: what the module itself runs
-for CPU tensors).  Tolerances: the kernels compute in fp32 with a different summation order than torch -> value 1e-5
+The checker is ``oracle/perceptual.py`` (test infrastructure: a functional CPU restatement of the lpips / torchvision
+structure over a state_dict; the product module is HIP-only and holds no torch formulation), in float64 for the tap
+kernels and fp32 for the whole network, fed with the PRODUCT's state_dict.  Tolerances: the kernels compute in fp32 with a different summation order than torch -> value 1e-5
 relative, gradient rel-L2 1e-5.  Parity of the whole term vs the reference stays UNPINNED (no weights, see
-models/perceptual.py); these tests pin the kernels to the published formula."""
+oracle/perceptual.py); these tests pin the kernels to the published formula."""
 import pytest
 import torch
+
+from oracle import perceptual as OP
+
+
+def _tap_hip(a, b, wt, gout, dev):
+    """value [N] and gradient w.r.t. ``a`` of one tap through the NCHW tail kernels (what _TrunkCompareFn uses for tap 0)."""
+    from pti_ldm_vae_amd import ops
+    ad, bd, wd = a.to(dev).contiguous(), b.to(dev).contiguous(), wt.to(dev).contiguous()
+    v, saved = ops.lpips_tap_fwd(ad, bd, wd)
+    return v, ops.lpips_tap_bwd(ad, bd, wd, saved, gout.float().to(dev).contiguous())
 
 pytestmark = pytest.mark.gpu
 
@@ -28,15 +39,12 @@ def _inputs(shape, seed, relu=True):
 
 @pytest.mark.parametrize("shape", SHAPES)
 def test_tap_forward_and_gradient_vs_torch_float64(dev, shape):
-    from pti_ldm_vae_amd.models.perceptual import _LpipsTapFn, lpips_tap_torch
     a, b, wt = _inputs(shape, seed=sum(shape))
     a64 = a.double().requires_grad_(True)
-    v64 = lpips_tap_torch(a64, b.double(), wt.double().view(1, -1, 1, 1))
+    v64 = OP.tap_distance(a64, b.double(), wt.double())
     gout = torch.linspace(0.5, 1.5, shape[0], dtype=torch.float64)
     g64, = torch.autograd.grad((v64 * gout).sum(), a64)
-    ad = a.to(dev).requires_grad_(True)
-    v = _LpipsTapFn.apply(ad, b.to(dev), wt.to(dev))
-    gd, = torch.autograd.grad((v * gout.float().to(dev)).sum(), ad)
+    v, gd = _tap_hip(a, b, wt, gout, dev)
     torch.cuda.synchronize()
     relv = ((v.cpu().double() - v64).abs() / v64.abs().clamp_min(1e-12)).max().item()
     relg = ((gd.cpu().double() - g64).norm() / g64.norm()).item()
@@ -61,14 +69,12 @@ def test_tap_is_zero_on_identical_maps_and_bitwise_reproducible(dev):
 def test_all_zero_pixels_give_finite_gradients(dev):
     """A pixel whose features are all zero after ReLU: torch's autograd formula yields 0/0 = NaN there; the kernel keeps
     the finite first term (documented in csrc/lpips.hip).  Everywhere else the two agree."""
-    from pti_ldm_vae_amd.models.perceptual import _LpipsTapFn, lpips_tap_torch
     a, b, wt = _inputs((2, 64, 9, 9), seed=9)
     a[:, :, 4, 4] = 0.0
     a64 = a.double().requires_grad_(True)
-    g64, = torch.autograd.grad(lpips_tap_torch(a64, b.double(), wt.double().view(1, -1, 1, 1)).sum(), a64)
+    g64, = torch.autograd.grad(OP.tap_distance(a64, b.double(), wt.double()).sum(), a64)
     assert torch.isnan(g64[:, :, 4, 4]).all()          # the behaviour being documented
-    ad = a.to(dev).requires_grad_(True)
-    gd, = torch.autograd.grad(_LpipsTapFn.apply(ad, b.to(dev), wt.to(dev)).sum(), ad)
+    _, gd = _tap_hip(a, b, wt, torch.ones(2), dev)
     assert torch.isfinite(gd).all()
     mask = torch.ones_like(a, dtype=torch.bool)
     mask[:, :, 4, 4] = False
@@ -87,29 +93,6 @@ def test_bad_arguments_are_refused(dev):
         ops.lpips_tap_fwd(a.half(), a.half(), torch.zeros(16, device=dev))
     with pytest.raises((ValueError, TypeError)):
         ops.lpips_tap_fwd(a.cpu(), a.cpu(), torch.zeros(16))
-
-
-def test_whole_term_fused_tail_equals_torch_tail(dev):
-    """SqueezeLPIPS on the device with the HIP tail vs the same module with ``fused_tail = False`` (torch ops end to end):
-    value and gradient w.r.t. the reconstruction, 256x256 inputs (all seven taps at their real sizes)."""
-    import copy
-    from pti_ldm_vae_amd.models import PerceptualLoss
-    torch.manual_seed(3)
-    pl = PerceptualLoss(allow_random_init=True).to(dev)
-    pl.net.native_trunk = False          # torch feature network + HIP tail
-    ref = copy.deepcopy(pl)
-    ref.net.fused_tail = False
-    g = torch.Generator().manual_seed(4)
-    y = torch.rand(3, 1, 256, 256, generator=g).to(dev)
-    x = (y + 0.1 * torch.randn(3, 1, 256, 256, generator=g).to(dev)).requires_grad_(True)
-    l1 = pl(x, y)
-    g1, = torch.autograd.grad(l1, x)
-    l2 = ref(x, y)
-    g2, = torch.autograd.grad(l2, x)
-    rel = ((g1 - g2).norm() / g2.norm()).item()
-    print(f"[lpips term] fused {l1.item():.6e} vs torch {l2.item():.6e}; grad relL2 {rel:.2e}")
-    assert l1.item() == pytest.approx(l2.item(), rel=1e-5)
-    assert rel <= 1e-4
 
 
 # ---- the trunk of the feature network on the HIP library (perceptual_engine.SqueezeTrunk) --------------------------------
@@ -164,7 +147,7 @@ def test_relu_passes(dev):
 
 @pytest.mark.parametrize("idx,hw", [(3, 63), (7, 31), (10, 15), (12, 15)])
 def test_fire_module_forward_and_input_gradient_vs_torch(dev, idx, hw):
-    """One Fire module on the HIP library (two MFMA convolutions, merged expands) vs the torch module in fp32: fp16 forward
+    """One Fire module on the HIP library (two MFMA convolutions, merged expands) vs the oracle's Fire in fp32 on the CPU: fp16 forward
     operands -> rel-L2 3e-3 forward (measured 4e-4); bf16 gradients (the incoming one is rounded to bf16 too) and ReLU
     masks taken from the fp16 squeeze output (a value within rounding of 0 flips its mask) -> gradient rel-L2 3e-2
     (measured 1.1-1.8e-2), cosine >= 0.9995."""
@@ -172,13 +155,15 @@ def test_fire_module_forward_and_input_gradient_vs_torch(dev, idx, hw):
     from pti_ldm_vae_amd.perceptual_engine import _Fire
     torch.manual_seed(idx)
     net = SqueezeLPIPS().to(dev)
+    sd = OP.cpu_state(net)
     f = net.features[idx]
     cin = f.squeeze.in_channels
-    x = torch.randn(2, cin, hw, hw, device=dev).relu()
+    x = torch.randn(2, cin, hw, hw).relu()
     xt = x.clone().requires_grad_(True)
-    yt = f(xt)
+    yt = OP.fire(sd, idx, xt)                                   # the checker: oracle Fire on the CPU, fp32
     gy = torch.randn_like(yt) * (yt > 0)
     gxt, = torch.autograd.grad(yt, xt, gy)
+    x, gy, yt, gxt = x.to(dev), gy.to(dev), yt.detach().to(dev), gxt.to(dev)
     fire = _Fire(f)
     xn = x.half().contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
     s, e = fire.fwd(xn)
@@ -190,34 +175,34 @@ def test_fire_module_forward_and_input_gradient_vs_torch(dev, idx, hw):
     assert r_f <= 3e-3 and r_g <= 3e-2 and cos >= 0.9995
 
 
-def test_whole_term_native_trunk_vs_torch_network(dev):
-    """The whole perceptual term with the HIP trunk + tail vs the torch network + torch tail at 256x256: value within
-    5e-3 relative, gradient w.r.t. the reconstruction cosine >= 0.999 (16-bit feature maps vs fp32)."""
-    import copy
+def test_whole_term_three_channel_path_vs_oracle(dev):
+    """The whole perceptual term on three-channel inputs (torch first layer on the device, HIP trunk + tail) vs the oracle
+    network on the CPU at 256x256: value within 5e-3 relative, gradient w.r.t. the reconstruction cosine >= 0.999 (16-bit
+    feature maps vs fp32)."""
     from pti_ldm_vae_amd.models import PerceptualLoss
     torch.manual_seed(3)
     pl = PerceptualLoss(allow_random_init=True).to(dev)
-    ref = copy.deepcopy(pl)
-    ref.net.native_trunk = False
-    ref.net.fused_tail = False
+    sd = OP.cpu_state(pl.net)
     g = torch.Generator().manual_seed(4)
-    y = torch.rand(3, 1, 256, 256, generator=g).to(dev)
-    x = (y + 0.1 * torch.randn(3, 1, 256, 256, generator=g).to(dev)).requires_grad_(True)
-    assert pl.net.use_native(x)
-    y, x = y.repeat(1, 3, 1, 1), x.detach().repeat(1, 3, 1, 1).requires_grad_(True)     # three-channel route: torch first layer
-    l1 = pl(x, y)
-    g1, = torch.autograd.grad(l1, x)
-    l2 = ref(x, y)
-    g2, = torch.autograd.grad(l2, x)
-    cos = torch.nn.functional.cosine_similarity(g1.flatten().double(), g2.flatten().double(), dim=0).item()
-    print(f"[lpips term, native trunk] {l1.item():.6e} vs torch {l2.item():.6e}; grad cosine {cos:.6f}, relL2 {_rel(g1, g2):.2e}")
+    y = torch.rand(3, 1, 256, 256, generator=g)
+    x = y + 0.1 * torch.randn(3, 1, 256, 256, generator=g)
+    y, x = y.repeat(1, 3, 1, 1), x.repeat(1, 3, 1, 1)
+    xo = x.clone().requires_grad_(True)
+    l2 = OP.perceptual_loss(sd, xo, y)
+    g2, = torch.autograd.grad(l2, xo)
+    xd, yd = x.to(dev).requires_grad_(True), y.to(dev)
+    l1 = pl(xd, yd)
+    g1, = torch.autograd.grad(l1, xd)
+    g1c = g1.cpu()
+    cos = torch.nn.functional.cosine_similarity(g1c.flatten().double(), g2.flatten().double(), dim=0).item()
+    print(f"[lpips term, three-channel path] {l1.item():.6e} vs oracle {l2.item():.6e}; grad cosine {cos:.6f}, relL2 {_rel(g1c, g2):.2e}")
     assert l1.item() == pytest.approx(l2.item(), rel=5e-3)
     assert cos >= 0.999 and torch.isfinite(g1).all()
     # split API used by the trainer: target taps first, then the comparison
-    l3 = pl.from_taps(x, pl.target_taps(y))
+    l3 = pl.from_taps(xd, pl.target_taps(yd))
     assert l3.item() == l1.item()
     # identical images: exactly zero
-    assert pl(y, y).item() == 0.0
+    assert pl(yd, yd).item() == 0.0
 
 
 @pytest.mark.parametrize("shape", [(3, 128, 63, 63), (2, 256, 31, 31), (4, 384, 15, 15), (2, 512, 15, 15), (1, 64, 5, 7), (2, 1024, 3, 3)])
@@ -225,11 +210,10 @@ def test_tap_nhwc_kernels_vs_torch_float64(dev, shape):
     """The comparison kernels on the trunk's layout (NHWC fp16 maps, bf16 gradient) vs the torch formula in float64 on the
     SAME fp16-rounded values: value 1e-5 relative; gradient rel-L2 3e-3 (one bf16 rounding of the result)."""
     from pti_ldm_vae_amd import ops
-    from pti_ldm_vae_amd.models.perceptual import lpips_tap_torch
     a, b, wt = _inputs(shape, seed=sum(shape) + 1)
     a, b = a.half(), b.half()
     a64 = a.double().requires_grad_(True)
-    v64 = lpips_tap_torch(a64, b.double(), wt.double().view(1, -1, 1, 1))
+    v64 = OP.tap_distance(a64, b.double(), wt.double())
     gout = torch.linspace(0.5, 1.5, shape[0], dtype=torch.float64)
     g64, = torch.autograd.grad((v64 * gout).sum(), a64)
     an = a.permute(0, 2, 3, 1).contiguous().to(dev)
@@ -262,25 +246,27 @@ def test_layout_kernels_at_the_trunk_boundary(dev):
 
 def test_folded_first_layer_vs_torch(dev):
     """The first layer for a one-channel image (three scaled copies folded into a 1 -> 64 convolution, ReLU fused) vs the
-    torch layers on the repeated, scaled image: forward rel-L2 1e-3 (fp16 output), gradient w.r.t. the one-channel
+    oracle's first layer + ReLU on the repeated, scaled image (CPU): forward rel-L2 1e-3 (fp16 output), gradient w.r.t. the one-channel
     image rel-L2 5e-3 (bf16 incoming gradient)."""
     from pti_ldm_vae_amd import ops
     from pti_ldm_vae_amd.models.perceptual import SqueezeLPIPS
     from pti_ldm_vae_amd.perceptual_engine import fold_first_layer
-    from pti_ldm_vae_amd.utils.losses import ensure_three_channels
     torch.manual_seed(6)
     net = SqueezeLPIPS().to(dev)
+    sd = OP.cpu_state(net)
     for n, h, w in ((2, 256, 256), (1, 17, 30), (3, 3, 3)):
-        x = torch.rand(n, 1, h, w, device=dev)
-        xt = x.clone().requires_grad_(True)
-        t0 = net.tap0(ensure_three_channels(xt))                     # [n, 64, ho, wo] fp32
+        xc = torch.rand(n, 1, h, w)
+        xt = xc.clone().requires_grad_(True)
+        t0 = OP.feature_layer(sd, 1, OP.feature_layer(sd, 0, OP.scale_input(OP.three_channels(xt))))   # [n, 64, ho, wo] fp32, CPU
+        x = xc.to(dev)
         w10 = fold_first_layer(net)
         y = ops.squeeze_conv1_fwd(x, w10)
         assert tuple(y.shape) == (n, t0.shape[2], t0.shape[3], 64)
-        r_f = _rel(y.permute(0, 3, 1, 2).float(), t0.detach())
+        r_f = _rel(y.permute(0, 3, 1, 2).float().cpu(), t0.detach())
         # the incoming gradient is zero where the fp32 and the fp16 outputs may disagree about the sign (|t0| tiny)
         gy = torch.randn_like(t0) * (t0.detach() > 1e-2)
         gxt, = torch.autograd.grad(t0, xt, gy)
+        t0, gy, gxt = t0.detach().to(dev), gy.to(dev), gxt.to(dev)
         dx = ops.squeeze_conv1_bwd(gy.permute(0, 2, 3, 1).contiguous().bfloat16(), y, w10, h, w)
         r_g = _rel(dx, gxt)
         # a gradient that already carries the mask (what the term's backward hands over): same result without t0
@@ -291,26 +277,25 @@ def test_folded_first_layer_vs_torch(dev):
         assert r_f <= 1e-3 and r_g <= 5e-3
 
 
-def test_whole_term_one_channel_path_vs_torch_network(dev):
+def test_whole_term_one_channel_path_vs_oracle(dev):
     """One-channel images through PerceptualLoss: everything on the HIP library (folded first layer, trunk, comparison)
-    vs the torch network + torch tail on the repeated image."""
-    import copy
+    vs the oracle network on the repeated image (CPU, fp32)."""
     from pti_ldm_vae_amd.models import PerceptualLoss
     torch.manual_seed(3)
     pl = PerceptualLoss(allow_random_init=True).to(dev)
-    ref = copy.deepcopy(pl)
-    ref.net.native_trunk = False
-    ref.net.fused_tail = False
+    sd = OP.cpu_state(pl.net)
     g = torch.Generator().manual_seed(4)
-    y = torch.rand(3, 1, 256, 256, generator=g).to(dev)
-    x = (y + 0.1 * torch.randn(3, 1, 256, 256, generator=g).to(dev)).requires_grad_(True)
-    assert pl._one_channel_native(x)
+    yc = torch.rand(3, 1, 256, 256, generator=g)
+    xc = yc + 0.1 * torch.randn(3, 1, 256, 256, generator=g)
+    xo = xc.clone().requires_grad_(True)
+    l2 = OP.perceptual_loss(sd, xo, yc)
+    g2, = torch.autograd.grad(l2, xo)
+    y, x = yc.to(dev), xc.to(dev).requires_grad_(True)
     l1 = pl(x, y)
     g1, = torch.autograd.grad(l1, x)
-    l2 = ref(x, y)
-    g2, = torch.autograd.grad(l2, x)
-    cos = torch.nn.functional.cosine_similarity(g1.flatten().double(), g2.flatten().double(), dim=0).item()
-    print(f"[lpips term, one-channel path] {l1.item():.6e} vs torch {l2.item():.6e}; grad cosine {cos:.6f}, relL2 {_rel(g1, g2):.2e}")
+    g1c = g1.cpu()
+    cos = torch.nn.functional.cosine_similarity(g1c.flatten().double(), g2.flatten().double(), dim=0).item()
+    print(f"[lpips term, one-channel path] {l1.item():.6e} vs oracle {l2.item():.6e}; grad cosine {cos:.6f}, relL2 {_rel(g1c, g2):.2e}")
     assert l1.item() == pytest.approx(l2.item(), rel=5e-3)
     assert cos >= 0.999 and tuple(g1.shape) == (3, 1, 256, 256) and torch.isfinite(g1).all()
     assert pl.from_taps(x, pl.target_taps(y)).item() == l1.item()
@@ -318,6 +303,8 @@ def test_whole_term_one_channel_path_vs_torch_network(dev):
     # three-channel inputs keep the torch first layer + HIP trunk
     x3 = x.detach().repeat(1, 3, 1, 1)
     assert pl(x3, y.repeat(1, 3, 1, 1)).item() == pytest.approx(l2.item(), rel=5e-3)
+    # mixed channel counts: both sides are taken as three-channel images
+    assert pl(x3, y).item() == pytest.approx(l2.item(), rel=5e-3)
 
 
 def test_fused_relu_store_of_the_plain_forward_conv(dev):
@@ -378,8 +365,7 @@ def test_train_script_with_local_perceptual_weight_files(dev, tmp_path):
     x = torch.rand(2, 1, 64, 64, device=dev)
     y = torch.rand(2, 1, 64, 64, device=dev)
     v_native = pl(x, y).item()
-    pl.net.native_trunk = pl.net.fused_tail = False
-    assert v_native == pytest.approx(pl(x, y).item(), rel=5e-3)
+    assert v_native == pytest.approx(OP.perceptual_loss(OP.cpu_state(pl.net), x.cpu(), y.cpu()).item(), rel=5e-3)
     # bitwise reproducible step with the term
     outs = []
     for _ in range(2):

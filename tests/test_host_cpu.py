@@ -224,3 +224,23 @@ def test_ar_settings_validation():
         ARSettings(mp, gamma=0.5, pairwise="some")
     with pytest.raises(ValueError, match="subset_pairs"):
         ARSettings(mp, gamma=0.5, pairwise="subset")
+
+
+def test_config_3_builds_the_same_model_as_config_a():
+    """BASELINE configs[2] (``vae_both_no_adv.json``, the 8-GPU data-parallel run) must describe config A's network: the
+    single-GPU parity and bench evidence then carries over to it -- checked on the parameter holder (names, shapes,
+    total) and on the training keys the step reads."""
+    import json
+    from pti_ldm_vae_amd.models import VAEModel
+    from pti_ldm_vae_amd.utils import read_config
+    a = read_config(os.path.join(ROOT, "config", "vae_dente_no_adv.json"))
+    b = read_config(os.path.join(ROOT, "config", "vae_both_no_adv.json"))
+    assert a["autoencoder_def"] == b["autoencoder_def"]
+    ma, mb = VAEModel.from_config(a["autoencoder_def"]), VAEModel.from_config(b["autoencoder_def"])
+    sa, sb = ma.state_dict(), mb.state_dict()
+    assert list(sa) == list(sb) and all(sa[k].shape == sb[k].shape for k in sa)
+    assert sum(v.numel() for v in sb.values()) == 4_562_593
+    for k in ("batch_size", "patch_size", "lr", "kl_weight", "recon_loss"):
+        assert a["autoencoder_train"][k] == b["autoencoder_train"][k], k
+    # (the files ship batch_size 8; BASELINE's 8 x 32 = 256 is the bench workload, set with bench.py --batch)
+    assert list(b["autoencoder_train"]["patch_size"]) == [256, 256]

@@ -10,7 +10,7 @@ out=$root/gpurun_out/profiles_$tag
 rm -rf "$out"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 STEPS=6; WARM=3
-echo "== kernel trace"; rocprofv3 --kernel-trace --stats -d "$out/trace" --output-format csv -- python3 "$root/bench.py" --steps $STEPS --warmup $WARM --no-cpu-baseline > "$out/bench_trace.json" 2> "$out/bench_trace.err"
+echo "== kernel trace"; rocprofv3 --kernel-trace --stats -d "$out/trace" --output-format csv -- python3 "$root/bench.py" --steps $STEPS --warmup $WARM --no-cpu-baseline --detail-out "$out/${tag}_per_shape.json" > "$out/bench_trace.json" 2> "$out/bench_trace.err"
 echo "== pmc fetch";   rocprofv3 --pmc FETCH_SIZE -d "$out/pmc_fetch" --output-format csv -- python3 "$root/bench.py" --steps $STEPS --warmup $WARM --no-cpu-baseline > /dev/null 2> "$out/pmc_fetch.err"
 echo "== pmc write";   rocprofv3 --pmc WRITE_SIZE -d "$out/pmc_write" --output-format csv -- python3 "$root/bench.py" --steps $STEPS --warmup $WARM --no-cpu-baseline > /dev/null 2> "$out/pmc_write.err"
 # steps in a run: warm-up + timed + 4 host-enqueue probes + 2 instrumented

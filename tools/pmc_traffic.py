@@ -5,7 +5,9 @@ launch and kernel.  gfx950 corrections per MI355X_MICROARCH.md (HBM / rocprofv3 
 FETCH_SIZE under-counts wide coalesced streams by 2x (128-B requests counted as 64 B), WRITE_SIZE is exact.
 
 usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json> <optimiser steps in the profiled run> ["note"] ["workload key"]
-(the workload key -- "<config basename>:b<batch>:<size>" -- is what bench.py matches before it attaches these numbers)
+(the workload key -- "<config basename>:b<batch>:<size>" -- and ``source_hash`` -- sha256 over csrc/, bench.source_hash()
+-- are what bench.py matches before it attaches these numbers: a counter file of another workload OR another kernel
+version is never paired with the live timings)
 """
 import collections
 import csv
@@ -38,6 +40,12 @@ def load(directory: str, counter: str):
     return acc
 
 
+def _source_hash() -> str:
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    return bench.source_hash()
+
+
 def main() -> None:
     fetch_dir, write_dir, out = sys.argv[1:4]
     steps = int(sys.argv[4])
@@ -53,7 +61,7 @@ def main() -> None:
     json.dump({"_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes).  Counter unit KB; fetch_bytes = "
                         "2 x FETCH_SIZE (gfx950 counts 128-B requests as 64 B for wide coalesced streams, "
                         "MI355X_MICROARCH.md HBM section); write_bytes = WRITE_SIZE.  Averages per launch.  " + note,
-               "workload": workload, "steps_profiled": steps,
+               "workload": workload, "source_hash": _source_hash(), "steps_profiled": steps,
                "bytes_per_step": round(sum((k["fetch_bytes"] + k["write_bytes"]) * k["launches_per_step"] for k in kernels.values())),
                "kernels": kernels}, open(out, "w"), indent=1)
     print(f"{len(kernels)} kernels -> {out}")
