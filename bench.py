@@ -122,10 +122,15 @@ def _pmc():
     return pmc
 
 
+CONV3X3 = "conv_mfma2_kernel+conv_ws128_kernel"   # the MFMA conv: v2 kernel + its weight-stationary sibling for 128 -> 128
+
+
 def family(name):
-    """Kernel FUNCTION of an instantiation name: template arguments stripped."""
+    """Kernel FUNCTION of an instantiation name: template arguments stripped; the two kernels that together implement the
+    stride-1 MFMA convolution (conv_mfma.hip / conv_ws.hip, picked per layer shape) are one family."""
     i = name.find("<")
-    return (name if i < 0 else name[:i]).strip()
+    f = (name if i < 0 else name[:i]).strip()
+    return CONV3X3 if f in ("conv_mfma2_kernel", "conv_ws128_kernel") else f
 
 
 def roofline_from_profile(rec, steps):
@@ -184,13 +189,23 @@ def roofline_from_profile(rec, steps):
     by_time = sorted(fam, key=lambda k: -fam[k][0])
     # the conv families are priced against the MFMA peak even where their aggregate intensity sits under the ridge:
     # north_star states the conv target against it (hbm_frac / mixed_frac carry the other view)
-    roofline = roof(by_time[0], force_mfma="mfma" in by_time[0])
+    roofline = roof(by_time[0], force_mfma=by_time[0] == CONV3X3)
     roofline["kernel_name_source"] = "pti_last_kernel_name(), template arguments folded"
     roofline["traffic_source"] = (f"profiles/{PMC_TRAFFIC_FILE}: rocprofv3 --pmc, 2xFETCH_SIZE+WRITE_SIZE per launch" if pmc
                                   else "null: no counter file for this workload + library source")
     roofline["secondary"] = [{k: r[k] for k in ("kernel", "bound", "achieved", "unit", "frac", "traffic", "ms_per_step",
                                                  "launches_per_step")}
-                             for r in (roof(f, force_mfma="mfma" in f) for f in by_time[1:4])]
+                             for r in (roof(f, force_mfma=f == CONV3X3) for f in by_time[1:4])]
+    if by_time[0] == CONV3X3:      # the family's two kernels on their own (rocprofv3 lists them separately)
+        parts = {}
+        for name, (tsec, flops, nbytes, cnt) in inst.items():
+            p = parts.setdefault(name[:name.find("<")] if "<" in name else name, [0.0, 0.0, 0])
+            if family(name) == CONV3X3:
+                p[0] += tsec
+                p[1] += flops
+                p[2] += cnt
+        roofline["parts"] = {k: {"ms_per_step": round(v[0] / steps * 1e3, 3), "tflops": round(v[1] / v[0] / 1e12, 1),
+                                 "launches_per_step": round(v[2] / steps, 1)} for k, v in parts.items() if v[2]}
     detail = {"instantiations": {k: {"ms_per_step": round(v[0] / steps * 1e3, 3), "tflops": round(v[1] / v[0] / 1e12, 1),
                                      "gbs": round(v[2] / v[0] / 1e9), "launches": round(v[3] / steps, 2)}
                                  for k, v in sorted(inst.items(), key=lambda kv: -kv[1][0])}}

@@ -8,7 +8,7 @@ mkdir -p build
 pids=()
 for f in *.hip abi.cpp; do
   o=build/${f%.*}.o
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ pti_common.h -nt "$o" ] || [ ../../include/pti_vae.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ pti_common.h -nt "$o" ] || [ conv_common.h -nt "$o" ] || [ ../../include/pti_vae.h -nt "$o" ]; then
     ( hipcc $FLAGS -x hip -c "$f" -o "$o" ) &
     pids+=($!)
   fi

@@ -57,6 +57,23 @@ class FlatGradAllReducer:
         self.launched.append((s, e))
         self._works.append(dist.all_reduce(self.arena[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
+    def reduce_range(self, start: int, end: int):
+        """All-reduce arena[start:end] now, as ~bucket-sized asynchronous collectives (descending, like backward emits
+        them).  Used by the HIP-graph step mode: a whole region's gradients are final when its captured half has been
+        replayed, so there is nothing to coalesce -- the region goes out in ``bucket_bytes`` pieces that overlap the
+        next captured half."""
+        if self.world == 1 or end <= start:
+            return
+        self._flush()
+        hi = end
+        while hi > start:
+            lo = max(start, hi - self.bucket_elems)
+            if lo - start < self.bucket_elems // 4:      # do not leave a sliver as its own collective
+                lo = start
+            self.launched.append((lo, hi))
+            self._works.append(dist.all_reduce(self.arena[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            hi = lo
+
     def finish(self):
         """Send what is pending and make the current stream wait for every bucket."""
         if self.world == 1:

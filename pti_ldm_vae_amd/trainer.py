@@ -282,9 +282,11 @@ class VAETrainer:
         d_recon.add_(g, alpha=self.perceptual_weight)
         return p.detach()
 
-    def _plain_fwd_bwd(self, images, eps):
-        """zero_grad -> forward -> L1|L2 + kl_weight*KL -> backward, without any optional term and without host-side
-        decisions: the part of the step a HIP graph can hold.  Returns the [recon, kl] device pair."""
+    def _plain_fwd_dec_bwd(self, images, eps, join):
+        """First half of the plain step: zero_grad -> forward -> L1|L2 + kl_weight*KL -> DECODER backward, without any
+        optional term and without host-side decisions.  ``join``: wait for the side-stream weight gradients, so that the
+        post_quant + decoder region of the gradient arena is final when this returns (the data-parallel graph mode
+        all-reduces it between its two captured halves).  Returns (the [recon, kl] device pair, what the second half needs)."""
         net, eng = self.net, self.eng
         net.grad_arena.zero_()
         mu, sigma, c_enc = eng.encode_forward(images, save=True)
@@ -295,11 +297,21 @@ class VAETrainer:
         d_recon, d_mu, d_third = torch.empty_like(recon), torch.empty_like(mu), torch.empty_like(third)
         ops.vae_loss(recon, images, mu, third, out2, d_recon, d_mu, d_third, l2=self.l2, third_mode=self.third_mode,
                      kl_weight=self.kl_weight)
-        dz = eng.decode_backward(c_dec, d_recon, want_dz=True, join=False)
+        dz = eng.decode_backward(c_dec, d_recon, want_dz=True, join=join)
         d_sigma = d_third if net.third_output == "sigma" else d_third * (2.0 / sigma)
         d_mu = d_mu + dz
         d_sigma = torch.addcmul(d_sigma, dz, eps)
-        eng.encode_backward(c_enc, d_mu, d_sigma, want_dx=False)
+        return out2, (c_enc, d_mu, d_sigma)
+
+    def _plain_enc_bwd(self, carry):
+        """Second half: the ENCODER backward (joins the side stream)."""
+        c_enc, d_mu, d_sigma = carry
+        self.eng.encode_backward(c_enc, d_mu, d_sigma, want_dx=False)
+
+    def _plain_fwd_bwd(self, images, eps):
+        """The part of the plain step ONE HIP graph can hold (single GPU).  Returns the [recon, kl] device pair."""
+        out2, carry = self._plain_fwd_dec_bwd(images, eps, join=False)    # encode_backward's join covers the side stream
+        self._plain_enc_bwd(carry)
         return out2
 
     def _step_graphed(self, images, eps):
@@ -343,6 +355,56 @@ class VAETrainer:
         g.replay()
         return out2.clone()
 
+    def _step_graphed_dp(self, images, eps):
+        """Data-parallel form of ``_step_graphed`` (world > 1): the step is captured as TWO graphs with the collectives
+        eager between them -- [forward, loss, decoder backward] | all-reduce of the post_quant + decoder region in
+        ~bucket-sized asynchronous pieces | [encoder backward] | all-reduce of the encoder + quant region | join | Adam.
+        The decoder region's exchange (3/4 of the gradient bytes of config A) runs under the second graph, as the eager
+        callbacks arrange it; what the graphs remove is the eager step's ~5 ms of host enqueue per rank, which at N = 8
+        is no longer hidden behind a single process's GPU time.  None when this call must run eagerly."""
+        key = ("dp", tuple(images.shape), self.l2, self.kl_weight, self.third_mode, self.eng.wgrad_stream is None,
+               self.eng.wgrad_batch_max)
+        st = self._graphs.get(key)
+        if st is None:
+            if self._eager_steps < 2 or len(self._graphs) >= 4 or ops.KERNEL_PROFILE is not None:
+                return None
+            net = self.net
+            down = 2 ** (len(net.channels) - 1)
+            gx = images.detach().float().contiguous().clone()
+            geps = torch.zeros(images.shape[0], net.latent_channels, images.shape[2] // down, images.shape[3] // down,
+                               dtype=torch.float32, device=images.device)
+            torch.cuda.synchronize()
+            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            self.eng.packed_version = -1          # the re-pack launches are part of the first graph (see _step_graphed)
+            self.eng.grad_ready_cb = None
+            try:
+                with torch.cuda.graph(ga, capture_error_mode="thread_local"):
+                    out2, carry = self._plain_fwd_dec_bwd(gx, geps, join=True)
+                with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode="thread_local"):
+                    self._plain_enc_bwd(carry)
+            except Exception as ex:
+                import warnings
+                warnings.warn(f"HIP-graph capture of the data-parallel step failed ({ex!r}); continuing with eager launches")
+                self.step_graph = False
+                torch.cuda.synchronize()
+                return None
+            st = self._graphs[key] = (ga, gb, gx, geps, out2, carry)     # `carry` keeps the tensors crossing the seam alive
+        ga, gb, gx, geps, out2, _ = st
+        gx.copy_(images)
+        if eps is None:
+            geps.normal_(generator=self.gen)
+        else:
+            geps.copy_(eps)
+        red = self.reducer
+        (e_lo, e_hi), (d_lo, d_hi) = self.net.arena_regions()
+        red.begin_step()
+        ga.replay()
+        red.reduce_range(d_lo, d_hi)          # asynchronous: runs under the second graph
+        gb.replay()
+        red.reduce_range(e_lo, e_hi)
+        red.finish()
+        return out2.clone()
+
     def step(self, images: torch.Tensor, eps: torch.Tensor | None = None, attributes: dict | None = None,
              adversarial: bool = False):
         """One optimiser step on ``images`` [B,C,H,W] fp32 (already on the device).  Returns a dict of
@@ -360,10 +422,12 @@ class VAETrainer:
         plain = (self.world == 1 and self.ar is None and not adversarial
                  and not (self.perceptual is not None and self.perceptual_weight != 0.0))
         use_graph = self.step_graph is True or (self.step_graph == "auto" and images.shape[0] * images.shape[2] * images.shape[3] <= 6 * 65536)
-        if use_graph and plain and ops.KERNEL_PROFILE is None:
-            out2 = self._step_graphed(images, eps)
+        plain_dp = (self.world > 1 and self.ar is None and not adversarial
+                    and not (self.perceptual is not None and self.perceptual_weight != 0.0))
+        if use_graph and (plain or plain_dp) and ops.KERNEL_PROFILE is None:
+            out2 = self._step_graphed(images, eps) if plain else self._step_graphed_dp(images, eps)
             if out2 is not None:
-                self.opt.step(grad_scale=1.0)
+                self.opt.step(grad_scale=1.0 / self.world)
                 done = torch.cuda.Event()
                 done.record()
                 self._step_done.append(done)

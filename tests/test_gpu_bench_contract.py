@@ -40,7 +40,7 @@ def test_default_line_has_the_contract_keys(dev, monkeypatch, capsys, tmp_path):
     for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "secondary"):
         assert k in r, k
     assert "<" not in r["kernel"], "the roofline is keyed on the kernel FUNCTION, instantiations folded"
-    assert r["kernel"] == "conv_mfma2_kernel" and r["bound"] == "mfma"
+    assert r["kernel"].startswith("conv_mfma2_kernel") and r["bound"] == "mfma"
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and 0 <= r["frac"] <= 1.0
     assert r["achieved"] == pytest.approx(r["frac"] * r["peak"], rel=1e-2, abs=1e-4 * r["peak"])   # frac is rounded to 4 places
     assert r["traffic"] is None          # the committed counter passes belong to the batch-32 256x256 workload, not this one
@@ -55,7 +55,7 @@ def test_line_stays_under_4k_at_the_default_workload(dev, monkeypatch, capsys, t
     """The DEFAULT workload (config A, batch 32, 256x256: ~64 distinct (shape, kernel) rows) is the one the driver runs."""
     d = _run(monkeypatch, capsys, ["--cpu-steps", "1"], tmp_path, small=False)
     assert d["config"]["global_batch"] == 32 and "256x256x1" in d["config"]["workload"]
-    assert d["roofline"]["kernel"] == "conv_mfma2_kernel" and len(d["roofline"]["secondary"]) == 3
+    assert d["roofline"]["kernel"].startswith("conv_mfma2_kernel") and len(d["roofline"]["secondary"]) == 3
     assert d["cpu_baseline"]["value"] > 0
     assert len(json.load(open(tmp_path / "detail.json"))["per_shape"]) > 40
 
