@@ -469,9 +469,14 @@ def main():
     # the GPU with (the headline number above is measured WITH the overlap)
     side = trainer.eng.wgrad_stream
     trainer.eng.wgrad_stream = None
-    for _ in range(2):          # EVERY rank steps (the step contains collectives); only rank 0 records
+    # EVERY rank steps (the step contains collectives) and every rank takes the EAGER path: only rank 0 records, and the
+    # graph step mode would otherwise stay on for the other ranks, whose region-sized buckets do not match the eager
+    # callbacks' buckets (a collective mismatch: gloo aborts, RCCL hangs)
+    graph_mode, trainer.step_graph = trainer.step_graph, False
+    for _ in range(2):
         trainer.step(images, attributes=attrs, **step_kw)
     torch.cuda.synchronize()
+    trainer.step_graph = graph_mode
     trainer.eng.wgrad_stream = side
     if rank == 0:
         rec, ops.KERNEL_PROFILE = ops.KERNEL_PROFILE, None

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256, 1) void conv_ws128_kernel(ConvArgs a, int ntil
         const int g = need ? g0 + k : g0;
         const float sum = stat_f(st, 2 * g), sq = stat_f(st, 2 * g + 1);
         mean[k] = sum * a.inv_cnt;
-        rstd[k] = __builtin_amdgcn_rsqf(fmaxf(sq * a.inv_cnt - mean[k] * mean[k], 0.f) + a.eps);
+        rstd[k] = rsqrtf(fmaxf(sq * a.inv_cnt - mean[k] * mean[k], 0.f) + a.eps);   // (the v2 kernel's exact expression: same bits)
       }
 #pragma unroll
       for (int q = 0; q < 8; ++q) {

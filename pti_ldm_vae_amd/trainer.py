@@ -361,7 +361,11 @@ class VAETrainer:
         ~bucket-sized asynchronous pieces | [encoder backward] | all-reduce of the encoder + quant region | join | Adam.
         The decoder region's exchange (3/4 of the gradient bytes of config A) runs under the second graph, as the eager
         callbacks arrange it; what the graphs remove is the eager step's ~5 ms of host enqueue per rank, which at N = 8
-        is no longer hidden behind a single process's GPU time.  None when this call must run eagerly."""
+        is no longer hidden behind a single process's GPU time.  None when this call must run eagerly.
+        EVERY RANK MUST TAKE THE SAME PATH on the same step (the two paths cut the arena into different buckets): the
+        decision below depends only on state that is identical across ranks in a symmetric job -- the step count, the batch
+        shape, ``step_graph`` -- plus ``ops.KERNEL_PROFILE``, which a caller that profiles one rank must pair with
+        ``step_graph = False`` on all of them (bench.py does)."""
         key = ("dp", tuple(images.shape), self.l2, self.kl_weight, self.third_mode, self.eng.wgrad_stream is None,
                self.eng.wgrad_batch_max)
         st = self._graphs.get(key)

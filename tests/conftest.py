@@ -50,8 +50,12 @@ def pytest_collection_finish(session):
     outdir = tempfile.mkdtemp(prefix="pti_dp_job_")
     log = open(os.path.join(outdir, "job.log"), "w")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "tests", "dp_gpu_worker.py"), outdir]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port_b = s.getsockname()[1]
+    s.close()
+    # the launcher runs the two-rank worker, then `bench.py --gpus 2` in its one-GPU rehearsal form (tests/dp_jobs_launcher.py)
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "dp_jobs_launcher.py"), outdir, str(port), str(port_b)]
     _DP_JOB.update(proc=subprocess.Popen(cmd, stdout=log, stderr=subprocess.STDOUT, env=env, cwd=ROOT), outdir=outdir, log=log)
     # the single-rank job on the REAL backend (nccl = RCCL): tests/rccl_one_rank_worker.py
     s = socket.socket()

@@ -75,6 +75,28 @@ def main(outdir):
     dist.all_gather(both, chk)
     res["ranks_agree"] = bool(torch.equal(both[0], both[1]))
 
+    # ---- HIP-graph step mode under data parallelism: two captured halves, collectives eager in between ----
+    try:
+        pair = []
+        for graph in (False, True):
+            mg = build_model(dev)
+            trg = VAETrainer(mg, lr=LR, world_size=world, bucket_bytes=256 << 10)
+            trg.step_graph = graph
+            losses = [trg.step(xs, es)["loss"].item() for _ in range(3)]      # steps 0, 1 eager; step 2 captured + replayed
+            torch.cuda.synchronize()
+            pair.append((mg.autoencoder.grad_arena.detach().clone(), mg.autoencoder.param_arena.detach().clone(), losses,
+                         len(trg._graphs), sorted(trg.reducer.launched)))
+        (g_e, p_e, l_e, n_e, _), (g_g, p_g, l_g, n_g, spans) = pair
+        chk = torch.stack([g_g.double().sum(), p_g.double().sum()]).cpu()
+        both = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(both, chk)
+        res["graph_dp"] = {"ok": True, "graphs": [n_e, n_g], "loss_eager": l_e, "loss_graph": l_g,
+                           "grad_rel": ((g_g - g_e).norm() / g_e.norm()).item(), "param_maxdiff": (p_g - p_e).abs().max().item(),
+                           "ranks_agree": bool(torch.equal(both[0], both[1])), "launched": spans, "arena_len": g_g.numel()}
+    except Exception as ex:
+        import traceback
+        res["graph_dp"] = {"ok": False, "error": repr(ex), "trace": traceback.format_exc()}
+
     # ---- native trainer with the adversarial branch: the discriminator has its own arena, exchange and Adam ----
     try:
         from pti_ldm_vae_amd.models import PatchDiscriminator
