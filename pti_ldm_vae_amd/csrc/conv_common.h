@@ -108,7 +108,15 @@ struct Cfg2 {
   // costing a second one in the epilogue.  Lane-linear image [pixel][CT/8 pieces], swizzled on the SOURCE side.
   static constexpr int RT_OFF = STAT_OFF + 1024 + 256;   // accumulators (1 KiB) + float table of the input statistics
   static constexpr int RT_BYTES = MPX * CT * 2;
-  static constexpr int LDS_BYTES = RT_OFF + RT_BYTES;
+  // bias[CT] (fp32), copied from global once at kernel start: a per-lane global load in the epilogue is an L2 round trip that
+  // hipcc waits for with vmcnt(0) right at its use -- 8-16 SERIALISED round trips per tile in the round-2 kernels
+  static constexpr int BIAS_OFF = RT_OFF + RT_BYTES;
+  // gamma[CT] | beta[CT] of the fused GroupNorm-backward epilogue (same reason: 16-36 serialised loads per tile).  Lives in
+  // the tail of the halo region that the output tile does not cover when that tail is large enough (free once the main loop
+  // is over; keeps <3,64,64,2> at 40,960 B = four workgroups per CU), in its own 8*CT bytes otherwise.
+  static constexpr bool GT_IN_TAIL = HALO_BYTES - EPI_BYTES >= 8 * CT;
+  static constexpr int GT_OFF = GT_IN_TAIL ? EPI_BYTES : BIAS_OFF + 4 * CT;
+  static constexpr int LDS_BYTES = BIAS_OFF + 4 * CT + (GT_IN_TAIL ? 0 : 8 * CT);
 };
 
 

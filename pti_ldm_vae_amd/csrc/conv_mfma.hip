@@ -409,6 +409,17 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
   } else if (gn_on) {
     if (tid < 2 * a.g_groups) sfl[tid] = stat_f(a.g_stats, n * a.g_groups * 2 + tid);
   }
+  // epilogue parameters: bias -> LDS now (the first barrier below publishes it); gamma / beta of the fused GroupNorm
+  // backward -> two registers of the first CT threads now, LDS after the main loop (their slot may alias the halo tile)
+  float gq = 0.f, bq = 0.f;
+  if (gn_on) {
+    if (tid < CT) {
+      gq = a.g_gamma[ct * CT + tid];
+      bq = a.g_beta[ct * CT + tid];
+    }
+  } else if (a.bias) {
+    if (tid < CT) reinterpret_cast<float*>(smem + C::BIAS_OFF)[tid] = a.bias[ct * CT + tid];
+  }
   if (a.res) {
     // piece (p, c) of the residual tile -> LDS slot p*ENC + c, holding channel piece c ^ ((p >> 2) & (ENC-1)) (the
     // epilogue reads apply the same XOR: 8-byte reads of one piece column at a 64..256-byte pixel pitch would
@@ -622,6 +633,14 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
   const bool do_stats = (FM == 2 || FM == 3) ? false : a.out_stats != nullptr;   // data gradients feed no GroupNorm
   const int ocpg = do_stats ? a.Cout / a.out_groups : 1;
   __syncthreads();  // every wave is done with the halo tile
+  float* gtab = reinterpret_cast<float*>(smem + C::GT_OFF);   // gamma[CT] | beta[CT]
+  if (gn_on) {
+    if (tid < CT) {
+      gtab[tid] = gq;
+      gtab[CT + tid] = bq;
+    }
+    __syncthreads();
+  }
   // (A) the residual tile is already in LDS (rtile, LDS-DMA issued at kernel start; every barrier since drained it)
   const unsigned char* rtile = smem + C::RT_OFF;
   const int col0 = wn * 32 + 4 * hsel;   // channel within the CT tile
@@ -636,7 +655,8 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
     for (int q = 0; q < 4; ++q) {
       const int col = col0 + 8 * q, ch0 = ct * CT + col;
       float scv[4], shv[4], muv[4], rsv[4], l1[4] = {0.f, 0.f, 0.f, 0.f}, l2[4] = {0.f, 0.f, 0.f, 0.f};
-      gn_params<4>(sfl, a.g_gamma, a.g_beta, ch0, gcpg, a.g_inv_cnt, a.g_eps, scv, shv, muv, rsv);
+      // gamma / beta from the LDS copy (indexed by the channel within this cout tile; the group index still needs ch0)
+      gn_params<4>(sfl, gtab - ct * CT, gtab + CT - ct * CT, ch0, gcpg, a.g_inv_cnt, a.g_eps, scv, shv, muv, rsv);
 #pragma unroll
       for (int i = 0; i < PXF; ++i) {
         const int p = (2 * PXF * wm + 2 * i + (j >> 4)) * 16 + (j & 15);
@@ -687,7 +707,7 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
       const int col = col0 + 8 * q;
       float v0 = acc[i][4 * q + 0], v1 = acc[i][4 * q + 1], v2 = acc[i][4 * q + 2], v3 = acc[i][4 * q + 3];
       if (a.bias) {
-        const f32x4 b = *(const f32x4*)(a.bias + ct * CT + col);
+        const f32x4 b = *(const f32x4*)(smem + C::BIAS_OFF + col * 4);
         v0 += b[0]; v1 += b[1]; v2 += b[2]; v3 += b[3];
       }
       unsigned char* ep = etile + p * C::EPITCH + col * 2;

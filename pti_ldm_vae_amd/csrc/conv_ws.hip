@@ -33,7 +33,9 @@ constexpr int WS_ET_OFF = 2 * WS_HALO;                     // output tile, trans
 constexpr int WS_STAT_OFF = WS_ET_OFF + WC::EPI_BYTES;     // 1 KiB of group sums + 256 B float statistics table
 constexpr int WS_RT_OFF = WS_STAT_OFF + 1024 + 256;        // residual tile / GroupNorm input of the fused backward
 constexpr int WS_DUMMY_OFF = WS_RT_OFF + WC::RT_BYTES;     // 1 KiB sink for masked-off halo pieces (keeps the staging code branch-free)
-constexpr int WS_LDS = WS_DUMMY_OFF + 1024;
+constexpr int WS_SCT_OFF = WS_DUMMY_OFF + 1024;           // GroupNorm scale / shift of the tile being staged: [64 channel pairs]{sc0, sc1, sh0, sh1}
+constexpr int WS_AUX_OFF = WS_SCT_OFF + 1024;             // 512 B: bias[128] (forward / plain data gradient) or {mean, rstd}[groups] (fused GN backward)
+constexpr int WS_LDS = WS_AUX_OFF + 512;
 static_assert(WS_LDS <= 160 * 1024, "LDS budget");
 static_assert(WC::KBC == 72 && WC::HITERS == 12 && WC::EITERS == 8 && WC::MPX == 128 && WC::HW == 18, "tile geometry");
 
@@ -105,6 +107,7 @@ __global__ __launch_bounds__(256, 1) void conv_ws128_kernel(ConvArgs a, int ntil
 
   // ---- halo loader state (constant per thread): piece = 8 channels lc*8.. of halo pixel lp0 + 16*it ----
   int lc = tid & 15, lp0 = tid >> 4;       // (laundered per tile, see the tile loop: keeps derived addresses out of registers)
+  int tidv = tid, lanev = lane;
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<bf16*>(a.x), 0, (unsigned)a.N * (unsigned)a.H * (unsigned)a.W * 128u * 2u, 0x00020000);
   const unsigned rowb = (unsigned)a.W * 256u;
@@ -112,38 +115,35 @@ __global__ __launch_bounds__(256, 1) void conv_ws128_kernel(ConvArgs a, int ntil
   if constexpr (PRO != PTI_PRO_NONE) gshift = __builtin_ctz(128 / a.groups);     // channels per group: a power of two (host check)
   u32x4 raw[4];            // rolling slots: piece p in slot p & 3
   unsigned okmask = 0;
-  float sc[8], sh[8];
   int ld_vy0 = 0, ld_vx0 = 0;      // tile being loaded: origin of its halo in the (virtual) input, sample base offset
   unsigned ld_base = 0;
 
-  // per-tile part of the loader: origin / base of tile tl, and this thread's GroupNorm scale / shift for tl's sample
+  // per-tile part of the loader: origin / base of tile tl; and the loads for the GroupNorm scale / shift table of tl's
+  // sample: lane l of EVERY wave fetches the statistics / gamma / beta of channel pair l (6 registers); tbl_write turns
+  // them into {sc, sc, sh, sh} and stores entry l (the four waves store identical values: no branch, no race) -- once per
+  // tile instead of every thread deriving its 8 channels into 16 registers.  A barrier separates tbl_write from the slices.
+  float tb_sum = 0.f, tb_sq = 0.f;
+  f32x2 tb_g = {0.f, 0.f}, tb_b = {0.f, 0.f};
   auto halo_begin = [&](const Tile& tl) {
     ld_vy0 = tl.oy0 - pad_lo;
     ld_vx0 = tl.ox0 - pad_lo;
     ld_base = ((unsigned)tl.n * a.H * a.W * 128u + lc * 8) * 2u;
     okmask = 0;
     if constexpr (PRO != PTI_PRO_NONE) {
-      // this thread's 8 channels lie in 1 (>= 8 channels per group), 2 (4) or 4 (2) groups
-      const stat_t* st = a.in_stats + (size_t)tl.n * a.groups * 2;
-      const int g0 = (lc * 8) >> gshift;
-      float mean[4], rstd[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const bool need = (k == 0) || (gshift == 2 && k < 2) || (gshift == 1);
-        const int g = need ? g0 + k : g0;
-        const float sum = stat_f(st, 2 * g), sq = stat_f(st, 2 * g + 1);
-        mean[k] = sum * a.inv_cnt;
-        rstd[k] = rsqrtf(fmaxf(sq * a.inv_cnt - mean[k] * mean[k], 0.f) + a.eps);   // (the v2 kernel's exact expression: same bits)
-      }
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        float m, r;
-        if (gshift >= 3) { m = mean[0]; r = rstd[0]; }
-        else if (gshift == 2) { m = mean[q >> 2]; r = rstd[q >> 2]; }
-        else { m = mean[q >> 1]; r = rstd[q >> 1]; }
-        sc[q] = r * a.gamma[lc * 8 + q];      // (re-read per tile from L1/L2: 16 registers cheaper than keeping them)
-        sh[q] = a.beta[lc * 8 + q] - m * sc[q];
-      }
+      const int c0 = 2 * (tidv & 63);
+      const stat_t* st = a.in_stats + ((size_t)tl.n * a.groups + (c0 >> gshift)) * 2;
+      tb_sum = stat_f(st, 0);
+      tb_sq = stat_f(st, 1);
+      tb_g = *(const f32x2*)(a.gamma + c0);
+      tb_b = *(const f32x2*)(a.beta + c0);
+    }
+  };
+  auto tbl_write = [&]() {
+    if constexpr (PRO != PTI_PRO_NONE) {
+      const float mean = tb_sum * a.inv_cnt;
+      const float rstd = rsqrtf(fmaxf(tb_sq * a.inv_cnt - mean * mean, 0.f) + a.eps);
+      const float s0 = rstd * tb_g[0], s1 = rstd * tb_g[1];
+      *(f32x4*)(smem + WS_SCT_OFF + (tidv & 63) * 16) = f32x4{s0, s1, tb_b[0] - mean * s0, tb_b[1] - mean * s1};
     }
   };
   // load piece `it` of the tile set up by halo_begin into its slot
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256, 1) void conv_ws128_kernel(ConvArgs a, int ntil
   auto halo_dst = [&](int it, unsigned char* hb, bool enable) -> unsigned char* {
     const int p = lp0 + it * 16;
     const int hy = p / 18, hx = p - hy * 18;
-    return (enable && p < C::NP) ? hb + p * 256 + ((lc ^ (hx & 15)) << 4) : smem + WS_DUMMY_OFF + lane * 16;
+    return (enable && p < C::NP) ? hb + p * 256 + ((lc ^ (hx & 15)) << 4) : smem + WS_DUMMY_OFF + lanev * 16;
   };
   // dword d (channels 2d, 2d+1 of the piece) of piece `it`: GroupNorm affine (+SiLU) in place in its register slot
   // (out-of-image pieces keep their zeros through a select); the last dword writes the piece to LDS
@@ -176,13 +176,14 @@ __global__ __launch_bounds__(256, 1) void conv_ws128_kernel(ConvArgs a, int ntil
       const uint32_t w = raw[it & 3][d];
       float lo, hi;
       unpack2f(w, in_f16, lo, hi);
-      if constexpr (PRO == PTI_PRO_GN_SILU) {   // the v2 kernel's formula for this tile shape, so that both kernels give the same bits
-        const f32x2 o = gn_silu2(f32x2{lo, hi}, f32x2{sc[2 * d], sc[2 * d + 1]}, f32x2{sh[2 * d], sh[2 * d + 1]});
+      const f32x4 ss = *(const f32x4*)(smem + WS_SCT_OFF + (lc * 4 + d) * 16);     // {sc, sc, sh, sh} of channels lc*8 + 2d, +1
+      if constexpr (PRO == PTI_PRO_GN_SILU) {   // the v2 kernel's formula for this tile shape
+        const f32x2 o = gn_silu2(f32x2{lo, hi}, f32x2{ss[0], ss[1]}, f32x2{ss[2], ss[3]});
         lo = o[0];
         hi = o[1];
       } else {
-        lo = lo * sc[2 * d] + sh[2 * d];
-        hi = hi * sc[2 * d + 1] + sh[2 * d + 1];
+        lo = lo * ss[0] + ss[2];
+        hi = hi * ss[1] + ss[3];
       }
       const uint32_t tw = pack2f(lo, hi, OPH);
       uint32_t out = ((okmask >> it) & 1u) ? tw : w;
@@ -201,13 +202,18 @@ __global__ __launch_bounds__(256, 1) void conv_ws128_kernel(ConvArgs a, int ntil
   const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
       a.y, 0, ((unsigned)a.N * (unsigned)a.Ho * (unsigned)a.Wo * 128u * 2u) >> (a.pool2 ? 2 : 0), 0x00020000);
   int epc = tid & 15, epp0 = tid >> 4;   // epilogue store: piece epc of pixel epp0 + 16*it
-  int tidv = tid;
 
+  if constexpr (!gn_on) {      // bias -> LDS once (a global load in the epilogue is an exposed L2 round trip per tile here)
+    if (a.bias && tid < 128) reinterpret_cast<float*>(smem + WS_AUX_OFF)[tid] = a.bias[tid];
+  }
   // ================= prologue: stage the first tile =================
   int t = blockIdx.x;
-  Tile cur = decode(t);
   int buf = 0;
+  {
+  const Tile cur = decode(t);
   halo_begin(cur);
+  tbl_write();
+  __syncthreads();       // the scale / shift table (and the bias table)
 #pragma unroll
   for (int b4 = 0; b4 < 12; b4 += 4) {
 #pragma unroll
@@ -218,8 +224,10 @@ __global__ __launch_bounds__(256, 1) void conv_ws128_kernel(ConvArgs a, int ntil
       for (int d = 0; d < 4; ++d) halo_slice(it, d, smem, true);
   }
   __syncthreads();
+  }
 
   for (; t < ntiles; t += gridDim.x) {
+    const Tile cur = decode(t);      // (re-derived per tile: carried across the loop the five scalars end up spilled)
     unsigned char* hcur = smem + buf * WS_HALO;
     unsigned char* hnxt = smem + (buf ^ 1) * WS_HALO;
     const int tn = t + gridDim.x;
@@ -229,18 +237,30 @@ __global__ __launch_bounds__(256, 1) void conv_ws128_kernel(ConvArgs a, int ntil
     // offsets ...) is loop-invariant, and the compiler hoists it all out of the tile loop into registers this kernel does
     // not have (288 are weights): it then spills and reloads them around every use.  Making the seeds opaque per tile
     // keeps the 1-3 VALU instructions of each address next to its use instead.
-    asm volatile("" : "+v"(lc), "+v"(lp0), "+v"(pb), "+v"(tk[0]), "+v"(tk[1]), "+v"(tk[2]), "+v"(epc), "+v"(epp0), "+v"(tidv));
+    asm volatile("" : "+v"(lc), "+v"(lp0), "+v"(pb), "+v"(tk[0]), "+v"(tk[1]), "+v"(tk[2]), "+v"(epc), "+v"(epp0), "+v"(tidv), "+v"(lanev));
+    const int hsel = lanev >> 5, j = lanev & 31;      // (shadow the kernel-scope copies inside the tile loop)
 
     // ---- tile start: residual tile by LDS-DMA, per-tile tables, next tile's loads ----
-    reinterpret_cast<float*>(smem + WS_STAT_OFF)[tid] = 0.f;
-    float* sfl = reinterpret_cast<float*>(smem + WS_STAT_OFF + 1024);
+    reinterpret_cast<float*>(smem + WS_STAT_OFF)[tidv] = 0.f;
     if constexpr (gn_on) {
-      if (tid < 2 * a.g_groups) sfl[tid] = stat_f(a.g_stats, n * a.g_groups * 2 + tid);
+      // GroupNorm parameters of THIS tile's sample for the fused-backward epilogue: {scale, shift} per channel and
+      // {mean, rstd} per group, computed once by 128 threads into LDS (barrier (a) lies between this and the epilogue);
+      // per-lane global loads of gamma / beta / statistics in the epilogue were ~16 exposed L2 round trips per tile
+      if (tidv < 128) {
+        const int gsh = __builtin_ctz(128 / a.g_groups);
+        const int g = tidv >> gsh;
+        const float sum = stat_f(a.g_stats, (n * a.g_groups + g) * 2), sq = stat_f(a.g_stats, (n * a.g_groups + g) * 2 + 1);
+        const float mean = sum * a.g_inv_cnt;
+        const float rstd = __builtin_amdgcn_rsqf(fmaxf(sq * a.g_inv_cnt - mean * mean, 0.f) + a.g_eps);
+        const float scv = rstd * a.g_gamma[tidv];
+        *(f32x2*)(smem + WS_SCT_OFF + tidv * 8) = f32x2{scv, a.g_beta[tidv] - mean * scv};
+        if ((tidv & ((1 << gsh) - 1)) == 0) *(f32x2*)(smem + WS_AUX_OFF + g * 8) = f32x2{mean, rstd};
+      }
     }
     if (a.res) {
 #pragma unroll
       for (int it = 0; it < C::EITERS; ++it) {
-        const int slot = it * 256 + tid;
+        const int slot = it * 256 + tidv;
         const int p = slot >> 4, c = slot & 15;
         const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
         if (oy < a.Ho && ox < a.Wo) {
@@ -308,10 +328,20 @@ __global__ __launch_bounds__(256, 1) void conv_ws128_kernel(ConvArgs a, int ntil
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i] = mfma32<OPH>(wreg[kb], b1[i], acc[i]);
       }
-      if constexpr (SAVE && kb < 8) save_piece(kb);
+      // side output in the idle tap group 3 (k-blocks 24..31), NOT in group 0: the first slice (k-block 8) waits with
+      // vmcnt(0) -- hipcc does not count past an LDS-DMA in flight -- and would sit there until the stores had drained
+      if constexpr (SAVE && kb >= 24 && kb < 32) save_piece(kb - 24);
+      // the next tile's scale / shift table: its loads were issued at tile start; written here, under the MFMAs, and made
+      // visible by a RAW barrier two k-blocks later (__syncthreads() would add vmcnt(0) and drain the loads in flight)
+      if constexpr (PRO != PTI_PRO_NONE && kb == 5) tbl_write();
+      if constexpr (PRO != PTI_PRO_NONE && kb == 7) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
       if constexpr (wk.piece >= 0) halo_slice(wk.piece, wk.dword, hnxt, has_next);
       if constexpr (wk.issue >= 0) halo_issue(wk.issue);
-      constexpr int nv = (SAVE && kb < 8) ? 24 : ((wk.piece >= 0 && PRO != PTI_PRO_NONE) ? 16 : 0) + (wk.issue >= 0 ? 12 : 0);
+      constexpr int nv = (SAVE && kb >= 24 && kb < 32) ? 24 : ((wk.piece >= 0 && PRO != PTI_PRO_NONE) ? 16 : 0) + (wk.issue >= 0 ? 12 : 0)
+                         + ((PRO != PTI_PRO_NONE && kb == 5) ? 10 : 0);
       constexpr int K = (nv + 3) / 4;
       __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // DS read x 4
 #pragma unroll
@@ -333,14 +363,22 @@ __global__ __launch_bounds__(256, 1) void conv_ws128_kernel(ConvArgs a, int ntil
     float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f};
     float su1[4] = {0.f, 0.f, 0.f, 0.f}, su2[4] = {0.f, 0.f, 0.f, 0.f};
     if constexpr (gn_on) {
-      const int gcpg = 128 / a.g_groups;
+      const int gsh_g = __builtin_ctz(128 / a.g_groups);
       float* gsm = reinterpret_cast<float*>(smem + WS_STAT_OFF);   // [CT][2]
       float L[32];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int col = col0 + 8 * q;
         float scv[4], shv[4], muv[4], rsv[4], l1[4] = {0.f, 0.f, 0.f, 0.f}, l2[4] = {0.f, 0.f, 0.f, 0.f};
-        gn_params<4>(sfl, a.g_gamma, a.g_beta, col, gcpg, a.g_inv_cnt, a.g_eps, scv, shv, muv, rsv);
+        {
+          const f32x4 t0 = *(const f32x4*)(smem + WS_SCT_OFF + col * 8), t1 = *(const f32x4*)(smem + WS_SCT_OFF + col * 8 + 16);
+          scv[0] = t0[0]; shv[0] = t0[1]; scv[1] = t0[2]; shv[1] = t0[3];
+          scv[2] = t1[0]; shv[2] = t1[1]; scv[3] = t1[2]; shv[3] = t1[3];
+          const f32x2 m0 = *(const f32x2*)(smem + WS_AUX_OFF + (col >> gsh_g) * 8);
+          const f32x2 m2 = *(const f32x2*)(smem + WS_AUX_OFF + ((col + 2) >> gsh_g) * 8);   // (2 channels per group: a second group)
+          muv[0] = muv[1] = m0[0]; rsv[0] = rsv[1] = m0[1];
+          muv[2] = muv[3] = m2[0]; rsv[2] = rsv[3] = m2[1];
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int p = (2 * i + (j >> 4)) * 16 + (j & 15);
@@ -387,7 +425,7 @@ __global__ __launch_bounds__(256, 1) void conv_ws128_kernel(ConvArgs a, int ntil
           const int col = col0 + 8 * q;
           float v0 = acc[i][4 * q + 0], v1 = acc[i][4 * q + 1], v2 = acc[i][4 * q + 2], v3 = acc[i][4 * q + 3];
           if (a.bias) {
-            const f32x4 b = *(const f32x4*)(a.bias + col);
+            const f32x4 b = *(const f32x4*)(smem + WS_AUX_OFF + col * 4);
             v0 += b[0]; v1 += b[1]; v2 += b[2]; v3 += b[3];
           }
           unsigned char* ep = etile + p * C::EPITCH + col * 2;
@@ -444,7 +482,7 @@ __global__ __launch_bounds__(256, 1) void conv_ws128_kernel(ConvArgs a, int ntil
       // data gradient of conv(nearest-2x(x)): store the 2x2-sum-pooled tile (see conv_mfma2_kernel)
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
-        const int idx = tid + it * 256;
+        const int idx = tidv + it * 256;
         const int c8 = idx & 15, pp = idx >> 4;
         const int py = pp >> 3, px = pp & 7;
         const int oy = (oy0 >> 1) + py, ox = (ox0 >> 1) + px;
@@ -476,18 +514,17 @@ __global__ __launch_bounds__(256, 1) void conv_ws128_kernel(ConvArgs a, int ntil
       }
     }
     if constexpr (gn_on) {
-      if (tid < 2 * CT) {
+      if (tidv < 2 * CT) {
         const float* gsm = reinterpret_cast<const float*>(smem + WS_STAT_OFF);
-        a.g_sums[(((size_t)n * a.g_T + cur.ty * a.tiles_x + cur.tx) * 128) * 2 + tid] = gsm[tid];
+        a.g_sums[(((size_t)n * a.g_T + cur.ty * a.tiles_x + cur.tx) * 128) * 2 + tidv] = gsm[tidv];
       }
     } else if (do_stats) {
       const stat_t* sstat = reinterpret_cast<const stat_t*>(smem + WS_STAT_OFF);
       const int ng = 128 / ocpg;
-      if (tid < 2 * ng)
-        atomicAdd((unsigned long long*)&a.out_stats[(n * a.out_groups) * 2 + tid], (unsigned long long)sstat[tid]);
+      if (tidv < 2 * ng)
+        atomicAdd((unsigned long long*)&a.out_stats[(n * a.out_groups) * 2 + tidv], (unsigned long long)sstat[tidv]);
     }
     __syncthreads();   // (c) etile / tables are free for the next tile
-    cur = nxt;
     buf ^= 1;
   }
 }
@@ -547,6 +584,10 @@ int launch_conv_ws128(const ConvArgs& a0, hipStream_t st) {
   if (fwd && a.prologue == PTI_PRO_NONE) return ws_launch<1, PTI_PRO_NONE, false>(a, ntiles, grid, st);
   if (fwd && a.prologue == PTI_PRO_GN) return ws_launch<1, PTI_PRO_GN, false>(a, ntiles, grid, st);
   if (a.w_f16) return 1;
+  if (fm == 3) {
+    const int cpg = a.g_groups > 0 ? 128 / a.g_groups : 0;
+    if (a.g_groups <= 0 || 128 % a.g_groups || (cpg & (cpg - 1)) || cpg < 2) return 1;
+  }
   if (fm == 2 && a.prologue == PTI_PRO_NONE && !a.gn_mode && !a.out_stats) return ws_launch<2, PTI_PRO_NONE, false>(a, ntiles, grid, st);
   if (fm == 3 && a.prologue == PTI_PRO_NONE && a.gn_mode && !a.out_stats && !a.pool2) return ws_launch<3, PTI_PRO_NONE, false>(a, ntiles, grid, st);
   return 1;
