@@ -862,6 +862,289 @@ __global__ __launch_bounds__(512, 1) void wgrad_mfma4_kernel(W4Batch b) {
   }
 }
 
+// =============================================================================================
+// v5 (round 3): the two-output-channel-block jobs (Cout % 64 == 0) with ONE wave per SIMD.  Same workgroup <-> (job,
+// split, 64co x 32ci block) mapping, same 28-KB stage image, same ring, same slab format as wgrad_mfma4_kernel<true>;
+// what changes is who multiplies what:
+//   * 4 waves instead of 8; wave w owns output rows 2w, 2w+1 of the 8x16 tile for BOTH output-channel blocks and all
+//     nine taps: 18 accumulators = 288 registers (+ 2 for the bias) -- possible only at one wave per SIMD (512
+//     registers).  An x fragment now feeds up to 4 MFMAs (2 output rows x 2 blocks) instead of 2, a dy fragment 9 instead
+//     of... the same 9, but there are half as many waves reading: 16 fragment reads per 36 (+4) MFMAs per wave and tile
+//     = 64 KB of LDS reads per tile and CU, against 8 waves x 28 = 224 KB in the v4 kernel (its measured bound);
+//   * the barrier runs ONE TILE AHEAD: iteration `it` waits (counted vmcnt + raw s_barrier) for tile it+1, computes tile
+//     `it` (confirmed an iteration ago), and loads the first fragments of tile it+1 at the end of that compute -- with one
+//     wave per SIMD nothing else would hide the LDS round trip behind the barrier;
+//   * the issue order is pinned per fragment step (the two transposing reads of the x fragment two steps ahead, then this
+//     fragment's 2 or 4 MFMAs): hipcc otherwise sinks every read next to its MFMA.
+// MEASURED (round 3, MI355X, batch 32, tools/bench_wgrad_v5.py, interleaved A/B in one process; dw bit-identical to v4):
+//   64->64@128^2 79 -> 97 us, 128->128@64^2 86 -> 117 us, 128->128@128^2 226 -> 260 us, 256->256@64^2 225 -> 263 us:
+//   15-48 % SLOWER, by a nearly size-independent 25-35 us per launch.  3.5x fewer LDS reads bought nothing -- confirming
+//   round 2's finding that LDS read bandwidth is not the bound -- and fetching x fragments two steps ahead instead of one
+//   changed nothing either (the LDS round trip is not exposed).  What the one-wave-per-SIMD form loses is per-WORKGROUP
+//   fixed time: with ~2048 workgroups of 16-32 tiles each (the split that overlaps best with the data-gradient stream),
+//   ring fill, the first barrier and the cross-wave reduction of 288 accumulator registers per wave (1168 AGPR<->VGPR
+//   moves, 128 spilled registers in that tail) are paid eight times per CU with nothing beside them, where v4's second
+//   wave per SIMD covers them.  OFF by default (PTI_WGRAD_V5=1); kept because it is validated bit for bit and is the
+//   starting point for a persistent variant (one workgroup per CU walking several (job, split, block) items with the
+//   reduction of item k overlapped with the ring fill of item k+1), which is what the measurement points to.
+// =============================================================================================
+__global__ __launch_bounds__(256, 1) void wgrad_mfma5_kernel(W4Batch b) {
+  constexpr int HWp = TW + 2, NPX = 10 * HWp, PP = 64, XB = 12 * 1024, STG = W4_STG2, DP = W4_DP2, NST = W4_NST2;
+  static_assert(NST * STG <= W4_LDS && 7 * (DP - 1) <= 63, "ring must fit the LDS and the vmcnt counter");
+  const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
+  const int ng = b.ngrp[xcd];
+  if (ng == 0 || pos >= b.grp_start[xcd][ng]) return;
+  int gi = 0;
+  while (gi + 1 < ng && pos >= b.grp_start[xcd][gi + 1]) ++gi;
+  const unsigned gword = b.grp[xcd][gi];
+  const int jb = gword & 15, split = gword >> 4, cc = pos - b.grp_start[xcd][gi];
+  const W4Job& a = b.job[jb];
+  const int ci_tiles = a.Cin / 32;
+  typedef short v4s __attribute__((ext_vector_type(4)));
+  typedef short v8s __attribute__((ext_vector_type(8)));
+  __shared__ __attribute__((aligned(16))) unsigned char smem[W4_LDS];
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cot = cc / ci_tiles, cit = cc % ci_tiles;
+  const int co0 = 2 * cot * 32, ci0 = cit * 32;
+  const bool do_bias = (cit == 0);
+
+  // DMA slots of this lane: x pieces (instructions w, w+4, w+8 of the 12) and, per output-channel block, dy pieces (w, w+4 of 8)
+  int xhy[3], xhx[3], xrel[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int i = (w + 4 * k) * 64 + lane, p = i >> 2;
+    xhy[k] = p < NPX ? p / HWp : 1 << 20;
+    xhx[k] = p - (p / HWp) * HWp;
+    xrel[k] = ((xhy[k] - 1) * a.W + xhx[k] - 1) * a.Cin * 2 + (ci0 + (i & 3) * 8) * 2;
+  }
+  int dty[2], dtx[2], drel[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int i = (w + 4 * k) * 64 + lane, p = i >> 2;
+    dty[k] = p >> 4;
+    dtx[k] = p & 15;
+    drel[k] = (dty[k] * a.W + dtx[k]) * a.Cout * 2 + (co0 + (i & 3) * 8) * 2;
+  }
+  const unsigned char* xb = reinterpret_cast<const unsigned char*>(a.x);
+  const unsigned char* db = reinterpret_cast<const unsigned char*>(a.dy);
+  const unsigned char* zero = reinterpret_cast<const unsigned char*>(pti_wgrad_zero_page);
+  struct TilePos { const unsigned char* xt; const unsigned char* dt; int oy0, ox0; bool live, interior; };
+  auto locate = [&](int tile) -> TilePos {
+    TilePos tp;
+    tp.live = tile < a.ntiles;
+    int t = tp.live ? tile : 0;
+    const int tx_ = t % a.tiles_x; t /= a.tiles_x;
+    const int ty_ = t % a.tiles_y;
+    const int n = t / a.tiles_y;
+    tp.oy0 = ty_ * 8; tp.ox0 = tx_ * TW;
+    tp.xt = xb + ((size_t)(n * a.H + tp.oy0) * a.W + tp.ox0) * a.Cin * 2;
+    tp.dt = db + ((size_t)(n * a.H + tp.oy0) * a.W + tp.ox0) * a.Cout * 2;
+    tp.interior = tp.oy0 >= 1 && tp.ox0 >= 1 && tp.oy0 + 9 <= a.H && tp.ox0 + 17 <= a.W;
+    return tp;
+  };
+  // slot k of 7: 0..2 x pieces, 3..4 dy pieces of block 0, 5..6 dy pieces of block 1 (k is a compile-time constant)
+  auto issue_slot = [&](const TilePos& tp, int stage, int k) {
+    const unsigned sbase = lds0 + stage * STG + w * 1024;
+    if (k < 3) {
+      bool ok = tp.live && xhy[k] < 16;
+      if (!tp.interior) {
+        const int vy = tp.oy0 - 1 + xhy[k], vx = tp.ox0 - 1 + xhx[k];
+        ok = ok && vy >= 0 && vy < a.H && vx >= 0 && vx < a.W;
+      }
+      glds16(ok ? tp.xt + xrel[k] : zero, sbase + k * 4096);
+    } else {
+      const int blk = (k - 3) >> 1, kk = (k - 3) & 1;
+      bool ok = tp.live;
+      if (!tp.interior) ok = ok && tp.oy0 + dty[kk] < a.H && tp.ox0 + dtx[kk] < a.W;
+      glds16(ok ? tp.dt + drel[kk] + blk * 64 : zero, sbase + XB + blk * 8192 + kk * 4096);
+    }
+  };
+
+  // 18 accumulators (2 blocks x 9 taps): 16 of them fill the AGPR file and go through the MFMA builtin; hipcc gives every
+  // builtin MFMA of a kernel an AGPR destination (a VGPR-resident accumulator is copied in and out around each use: 32
+  // moves per MFMA), so the last two -- block 1, taps (2,1) and (2,2) -- are multiplied by an inline-asm MFMA in its
+  // VGPR-destination form.  The bias gradient is a per-lane VALU sum of the dy fragments (a lane of an A fragment holds 8
+  // pixels of ONE output channel): two registers instead of two more accumulators.
+  f32x16 accA[16], accV[2];
+  float bsum[2] = {0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    accV[0][r] = accV[1][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accA[i][r] = 0.f;
+  }
+  auto mma = [&](int idx, const bf16x8& am, const bf16x8& bm) {      // idx = block * 9 + kh * 3 + kw (compile-time)
+    if (idx < 16) accA[idx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, accA[idx], 0, 0, 0);
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(accV[idx - 16]) : "v"(am), "v"(bm));
+  };
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const int fbase = (8 * (g >> 1) + q) * PP + (16 * (g & 1) + 4 * pp) * 2;
+  bf16x8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
+  auto tr_frag = [&](const unsigned char* p) -> bf16x8 {
+    const v4s d0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(p));
+    const v4s d1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(p + 4 * PP));
+    const v8s t = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+    return __builtin_bit_cast(bf16x8, t);
+  };
+
+  const int ntl = a.ntiles > split ? (a.ntiles - split + a.S - 1) / a.S : 0;
+  auto tile_of = [&](int k) { return k < ntl ? split + k * a.S : a.ntiles; };   // (past the end: zeros)
+  // ring fill: tiles 0 .. DP-1
+#pragma unroll
+  for (int s = 0; s < DP; ++s) {
+    const TilePos tp = locate(tile_of(s));
+#pragma unroll
+    for (int k = 0; k < 7; ++k) issue_slot(tp, s, k);
+  }
+  // first fragments of a tile: the four dy fragments (2 output rows x 2 blocks) and x fragment 0 (halo row 2w, kw 0)
+  bf16x8 dfr[2][2], xcur;
+  auto first_frags = [&](int slot) {
+    const unsigned char* lA = smem + slot * STG;
+#pragma unroll
+    for (int oi = 0; oi < 2; ++oi)
+#pragma unroll
+      for (int bl = 0; bl < 2; ++bl) dfr[oi][bl] = tr_frag(lA + XB + bl * 8192 + fbase + (2 * w + oi) * TW * PP);
+    xcur = tr_frag(lA + fbase + (2 * w * HWp) * PP);
+  };
+  wait_vmcnt<7 * (DP - 1)>();           // tile 0 has landed (this wave's pieces) ...
+  __builtin_amdgcn_s_barrier();         // ... and everyone's
+  first_frags(0);
+
+  int ps = 0;
+  for (int it = 0; it < ntl; ++it) {
+    int fs = ps + DP;
+    fs = fs >= NST ? fs - NST : fs;
+    int ns = ps + 1 == NST ? 0 : ps + 1;
+    const TilePos ft = locate(tile_of(it + DP));
+    // tile it+1 has landed (tiles it+2, it+3 may fly), for every wave; every wave is also done reading tile it-1's slot,
+    // which this iteration refills with tile it+DP
+    wait_vmcnt<7 * (DP - 2)>();
+    __builtin_amdgcn_s_barrier();
+    const unsigned char* lA = smem + ps * STG;
+    if (do_bias) {
+#pragma unroll
+      for (int oi = 0; oi < 2; ++oi)
+#pragma unroll
+        for (int bl = 0; bl < 2; ++bl) {
+          const u32x4 dw = __builtin_bit_cast(u32x4, dfr[oi][bl]);
+          float s8 = 0.f;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) s8 += __uint_as_float(dw[i] << 16) + __uint_as_float(dw[i] & 0xffff0000u);
+          bsum[bl] += s8;
+        }
+    }
+    // 12 x fragments: halo rows 2w .. 2w+3 (rr) x kw; fragment f+2 is read while fragment f's MFMAs issue (two ahead:
+    // a transposing read takes longer to return than the 2 MFMAs of an edge fragment take to issue)
+    auto xfrag_at = [&](int f) { return tr_frag(lA + fbase + ((2 * w + f / 3) * HWp + f % 3) * PP); };
+    bf16x8 xq1 = xfrag_at(1);
+#pragma unroll
+    for (int f = 0; f < 12; ++f) {
+      const int rr = f / 3, kw = f % 3;
+      bf16x8 xq2 = xq1;
+      if (f + 2 < 12) xq2 = xfrag_at(f + 2);
+#pragma unroll
+      for (int oi = 0; oi < 2; ++oi) {
+        const int kh = rr - oi;       // halo row 2w+rr = output row 2w+oi + kh
+        if (kh >= 0 && kh < 3) {
+#pragma unroll
+          for (int bl = 0; bl < 2; ++bl)
+            mma(bl * 9 + kh * 3 + kw, dfr[oi][bl], xcur);
+        }
+      }
+      // this wave's 7 DMA pieces of tile it+DP, spread over the fragment steps
+      if (f == 1) issue_slot(ft, fs, 0);
+      if (f == 3) issue_slot(ft, fs, 1);
+      if (f == 5) issue_slot(ft, fs, 2);
+      if (f == 7) issue_slot(ft, fs, 3);
+      if (f == 8) issue_slot(ft, fs, 4);
+      if (f == 9) issue_slot(ft, fs, 5);
+      if (f == 10) issue_slot(ft, fs, 6);
+      if (f + 2 < 12) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                  // the fragment two ahead: two reads
+      {
+        const int nasm = (kw >= 1 && (rr == 2 || rr == 3)) ? 1 : 0;
+        const int nm = ((rr == 1 || rr == 2) ? 4 : 2) - nasm;
+        if (nm == 4) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        else if (nm == 3) __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        else if (nm == 2) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        else __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      xcur = xq1;
+      xq1 = xq2;
+    }
+    // first fragments of tile it+1 (its slot was confirmed by this iteration's barrier)
+    first_frags(ns);
+    ps = ns;
+  }
+  wait_vmcnt<0>();
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the inline-asm MFMAs' results, before compiler code reads accV
+  __syncthreads();                        // every wave is done with the ring: it becomes the reduction scratch
+
+  // ---- sum the four waves' partial blocks (both output-channel blocks each) in a fixed order and store the slab ----
+  // round 1: waves 2, 3 -> images (2w-4 .. ), waves 0, 1 add;  round 2: wave 1 -> images, wave 0 adds;  wave 0 -> final images
+  float* red = reinterpret_cast<float*>(smem);               // four fp32 images of 9216 floats
+  float* bred = red + 4 * 9216;                               // [4 waves][2 blocks][32] bias partials
+  const int ci = lane & 31, hsel = lane >> 5;
+#define AC(bl, kh, kw) (((bl) * 9 + (kh) * 3 + (kw)) < 16 ? accA[((bl) * 9 + (kh) * 3 + (kw)) & 15] : accV[((bl) * 9 + (kh) * 3 + (kw)) - 16 < 0 ? 0 : ((bl) * 9 + (kh) * 3 + (kw)) - 16])
+  auto dump = [&](float* img, int bl) {
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4)
+          *(f32x4*)(img + (kh * 3 + kw) * 1024 + ci * 32 + (((2 * q4 + hsel) ^ (ci & 7)) << 2)) =
+              f32x4{AC(bl, kh, kw)[4 * q4], AC(bl, kh, kw)[4 * q4 + 1], AC(bl, kh, kw)[4 * q4 + 2], AC(bl, kh, kw)[4 * q4 + 3]};
+  };
+  auto gather = [&](const float* img, int bl) {
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const f32x4 v = *(const f32x4*)(img + (kh * 3 + kw) * 1024 + ci * 32 + (((2 * q4 + hsel) ^ (ci & 7)) << 2));
+#pragma unroll
+          for (int j = 0; j < 4; ++j) AC(bl, kh, kw)[4 * q4 + j] += v[j];
+        }
+  };
+  if (do_bias) {       // lanes l and l + 32 hold the two pixel halves of output channel l
+#pragma unroll
+    for (int bl = 0; bl < 2; ++bl) {
+      const float t = bsum[bl] + __shfl_xor(bsum[bl], 32, 64);
+      if (lane < 32) bred[(w * 2 + bl) * 32 + lane] = t;
+    }
+  }
+  if (w >= 2) { dump(red + (2 * (w - 2)) * 9216, 0); dump(red + (2 * (w - 2) + 1) * 9216, 1); }
+  __syncthreads();
+  if (w < 2) { gather(red + (2 * w) * 9216, 0); gather(red + (2 * w + 1) * 9216, 1); }
+  __syncthreads();
+  if (w == 1) { dump(red, 0); dump(red + 9216, 1); }
+  __syncthreads();
+  if (w == 0) { gather(red, 0); gather(red + 9216, 1); }
+  __syncthreads();
+  if (w == 0) { dump(red, 0); dump(red + 9216, 1); }
+  __syncthreads();
+  // blocks (2*cot, cit) and (2*cot + 1, cit) of the 32 x 32 block grid: ci_tiles blocks apart in the slab
+  float* slab2 = a.slab + (size_t)split * a.slab_stride + (size_t)(2 * cot * ci_tiles + cit) * 9216;
+  for (int i4 = tid; i4 < 2 * 2304; i4 += 256) {
+    const int g2 = i4 >= 2304, j4 = i4 - g2 * 2304;
+    *(f32x4*)(slab2 + (size_t)g2 * ci_tiles * 9216 + j4 * 4) = *(const f32x4*)(red + g2 * 9216 + j4 * 4);
+  }
+  if (do_bias && tid < 64) {
+    const int g2 = tid >> 5;
+    float sm = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sm += bred[(k * 2 + g2) * 32 + (tid & 31)];
+    a.slab[(size_t)split * a.slab_stride + (size_t)9 * a.Cout * a.Cin + cot * 64 + tid] = sm;
+  }
+#undef AC
+}
+
 // Slab reduction of the v4 layout: slab s = [(co,ci) block cc][tap][ci][co quad ^ (ci & 7)][4 co] + Cout bias sums.
 // Same fixed-order scheme as wgrad_reduce_kernel (16 float4 columns x 16 slab groups per block).
 __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(W4Batch b) {
@@ -1145,7 +1428,10 @@ extern "C" int pti_conv_wgrad_mfma_partials(const void* x, const void* dy, const
     b.accumulate[0] = 0;
     if (w4_plan(b, (float*)workspace, workspace_bytes / 4) < 0)
       PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma: workspace too small (%lld bytes per split needed)", a.slab_stride * 4);
-    if (b.job[0].cob2) PTI_LAUNCH(wgrad_mfma4_kernel<true>, dim3(b.nwg), dim3(512), 0, (hipStream_t)s, b);
+    const char* v5e = getenv("PTI_WGRAD_V5");     // (read per call here: the A/B tool toggles it inside one process)
+    const bool v5 = v5e && atoi(v5e) != 0 && !b.diag;
+    if (b.job[0].cob2 && v5) PTI_LAUNCH(wgrad_mfma5_kernel, dim3(b.nwg), dim3(256), 0, (hipStream_t)s, b);
+    else if (b.job[0].cob2) PTI_LAUNCH(wgrad_mfma4_kernel<true>, dim3(b.nwg), dim3(512), 0, (hipStream_t)s, b);
     else PTI_LAUNCH(wgrad_mfma4_kernel<false>, dim3(b.nwg), dim3(512), 0, (hipStream_t)s, b);
     PTI_CHECK_LAUNCH("conv_wgrad_mfma");
     *splits_out = b.job[0].S | PTI_WGRAD_SLAB_V4;   // the reduction must know the slab layout
@@ -1232,13 +1518,24 @@ extern "C" int pti_conv_wgrad_mfma_batched(const pti_wgrad_job* jobs, int njobs,
     if (used < 0) PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma_batched: workspace too small");
     ws += used;
     ws_floats -= used;
-    if (m == 1) PTI_LAUNCH(wgrad_mfma4_kernel<true>, dim3(b.nwg), dim3(512), 0, (hipStream_t)s, b);
+    // two-block jobs: PTI_WGRAD_V5=1 selects the one-wave-per-SIMD kernel (v5; bit-identical results, measured 15-48 %
+    // SLOWER than v4 in round 3 -- see the note above wgrad_mfma5_kernel -- hence off by default)
+    const char* v5e = getenv("PTI_WGRAD_V5");
+    const int v5_env = v5e ? atoi(v5e) : 0;
+    if (m == 1 && v5_env && !b.diag) PTI_LAUNCH(wgrad_mfma5_kernel, dim3(b.nwg), dim3(256), 0, (hipStream_t)s, b);
+    else if (m == 1) PTI_LAUNCH(wgrad_mfma4_kernel<true>, dim3(b.nwg), dim3(512), 0, (hipStream_t)s, b);
     else PTI_LAUNCH(wgrad_mfma4_kernel<false>, dim3(b.nwg), dim3(512), 0, (hipStream_t)s, b);
     PTI_CHECK_LAUNCH("conv_wgrad_mfma_batched");
     PTI_LAUNCH(wgrad_reduce4_kernel, dim3(b.first_rblk[b.njobs]), dim3(256), 0, (hipStream_t)s, b);
     PTI_CHECK_LAUNCH("conv_wgrad_mfma_batched reduce");
   }
   // pti_last_kernel_name(): the call's main kernel
-  pti_last_kernel = bm[1].njobs ? reinterpret_cast<const void*>(wgrad_mfma4_kernel<true>) : reinterpret_cast<const void*>(wgrad_mfma4_kernel<false>);
+  {
+    const char* v5e2 = getenv("PTI_WGRAD_V5");
+    const int v5_env2 = v5e2 ? atoi(v5e2) : 0;
+    pti_last_kernel = bm[1].njobs ? ((v5_env2 && !bm[1].diag) ? reinterpret_cast<const void*>(wgrad_mfma5_kernel)
+                                                             : reinterpret_cast<const void*>(wgrad_mfma4_kernel<true>))
+                                  : reinterpret_cast<const void*>(wgrad_mfma4_kernel<false>);
+  }
   return PTI_OK;
 }
