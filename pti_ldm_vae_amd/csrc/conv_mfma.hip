@@ -657,6 +657,9 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
       float scv[4], shv[4], muv[4], rsv[4], l1[4] = {0.f, 0.f, 0.f, 0.f}, l2[4] = {0.f, 0.f, 0.f, 0.f};
       // gamma / beta from the LDS copy (indexed by the channel within this cout tile; the group index still needs ch0)
       gn_params<4>(sfl, gtab - ct * CT, gtab + CT - ct * CT, ch0, gcpg, a.g_inv_cnt, a.g_eps, scv, shv, muv, rsv);
+      float nmr[4];     // -mean * rstd: xhat = x * rstd + nmr
+#pragma unroll
+      for (int r = 0; r < 4; ++r) nmr[r] = -muv[r] * rsv[r];
 #pragma unroll
       for (int i = 0; i < PXF; ++i) {
         const int p = (2 * PXF * wm + 2 * i + (j >> 4)) * 16 + (j & 15);
@@ -676,13 +679,12 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
         const u32x2 packed = pack4(dv[0], dv[1], dv[2], dv[3]);
         *(u32x2*)ep = packed;
         if (inb) {
-          const float d0 = __uint_as_float(packed[0] << 16), d1 = __uint_as_float(packed[0] & 0xffff0000u);
-          const float d2 = __uint_as_float(packed[1] << 16), d3 = __uint_as_float(packed[1] & 0xffff0000u);
-          const float dd[4] = {d0, d1, d2, d3};
+          // sums of the fp32 values (not of their bf16 roundings: one unpack per value less on a VALU-bound epilogue; the
+          // difference is the rounding error of a sum of N terms, ~2^-9 / sqrt(N) relative), xhat as ONE fma per value
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            l1[r] += dd[r];
-            l2[r] += dd[r] * (xv[r] - muv[r]) * rsv[r];
+            l1[r] += dv[r];
+            l2[r] = fmaf(dv[r], fmaf(xv[r], rsv[r], nmr[r]), l2[r]);
           }
         }
       }

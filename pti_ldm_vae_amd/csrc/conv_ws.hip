@@ -379,6 +379,9 @@ __global__ __launch_bounds__(256, 1) void conv_ws128_kernel(ConvArgs a, int ntil
           muv[0] = muv[1] = m0[0]; rsv[0] = rsv[1] = m0[1];
           muv[2] = muv[3] = m2[0]; rsv[2] = rsv[3] = m2[1];
         }
+        float nmr[4];     // -mean * rstd: xhat = x * rstd + nmr
+#pragma unroll
+        for (int r = 0; r < 4; ++r) nmr[r] = -muv[r] * rsv[r];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int p = (2 * i + (j >> 4)) * 16 + (j & 15);
@@ -398,12 +401,12 @@ __global__ __launch_bounds__(256, 1) void conv_ws128_kernel(ConvArgs a, int ntil
           const u32x2 packed = pack4(dv[0], dv[1], dv[2], dv[3]);
           *(u32x2*)ep = packed;
           if (inb) {
-            const float dd[4] = {__uint_as_float(packed[0] << 16), __uint_as_float(packed[0] & 0xffff0000u),
-                                 __uint_as_float(packed[1] << 16), __uint_as_float(packed[1] & 0xffff0000u)};
+            // sums of the fp32 values (not of their bf16 roundings: one unpack per value less on a VALU-bound epilogue; the
+            // difference is the rounding error of a sum of N terms, ~2^-9 / sqrt(N) relative), xhat as ONE fma per value
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              l1[r] += dd[r];
-              l2[r] += dd[r] * (xv[r] - muv[r]) * rsv[r];
+              l1[r] += dv[r];
+              l2[r] = fmaf(dv[r], fmaf(xv[r], rsv[r], nmr[r]), l2[r]);
             }
           }
         }

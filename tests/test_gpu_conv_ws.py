@@ -55,9 +55,11 @@ def _same(ref, outs, what, prologue=False):
                 continue
             d = (a.double() - b.double()).abs()
             nbad, scale = int((d > 0).sum()), a.double().abs().max().item()
-            tol = 2e-4 if a.dtype == torch.int64 else 2.0 ** -8
-            assert nbad <= max(8, 5e-4 * d.numel()) or a.dtype == torch.int64, f"{what}: output {k}: {nbad} of {d.numel()} elements differ"
-            assert d.max().item() <= tol * scale, f"{what}: output {k}: max |diff| {d.max().item():.3e} (scale {scale:.3e})"
+            if a.dtype in (torch.int64, torch.float32):      # statistics / GroupNorm-backward sums: long sums of slightly different terms
+                assert d.max().item() <= 2e-4 * scale, f"{what}: output {k}: max |diff| {d.max().item():.3e} (scale {scale:.3e})"
+                continue
+            assert nbad <= max(8, 5e-4 * d.numel()), f"{what}: output {k}: {nbad} of {d.numel()} elements differ"
+            assert d.max().item() <= 2.0 ** -8 * scale, f"{what}: output {k}: max |diff| {d.max().item():.3e} (scale {scale:.3e})"
 
 
 FWD_CASES = [
