@@ -495,16 +495,11 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
     if (chunk == 0) __syncthreads();   // the float statistics table (sfl) is complete
     float sc[8], sh[8];
     if (prologue != PTI_PRO_NONE) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int ch = chunk * CK + lc * 8 + j;
-        const int g = ch / cpg;
-        const float sum = sfl[2 * g], sq = sfl[2 * g + 1];
-        const float mean = sum * a.inv_cnt;
-        const float rstd = rsqrtf(fmaxf(sq * a.inv_cnt - mean * mean, 0.f) + a.eps);
-        sc[j] = rstd * a.gamma[ch];
-        sh[j] = a.beta[ch] - mean * sc[j];
-      }
+      // per GROUP on a straight-line path per group size (shift for the group index, one v_rsq per group): the
+      // per-channel form -- integer division by the run-time channels-per-group and a guarded rsqrtf per channel --
+      // cost ~25 VALU instructions per channel on kernels that are VALU-bound
+      float mu_[8], rs_[8];
+      gn_params<8>(sfl, a.gamma, a.beta, chunk * CK + lc * 8, cpg, a.inv_cnt, a.eps, sc, sh, mu_, rs_);
     }
     if (chunk > 0) __syncthreads();  // every wave is done reading the previous chunk's halo
 #pragma unroll

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256, 1) void conv_ws128_kernel(ConvArgs a, int ntil
   auto tbl_write = [&]() {
     if constexpr (PRO != PTI_PRO_NONE) {
       const float mean = tb_sum * a.inv_cnt;
-      const float rstd = rsqrtf(fmaxf(tb_sq * a.inv_cnt - mean * mean, 0.f) + a.eps);
+      const float rstd = __builtin_amdgcn_rsqf(fmaxf(tb_sq * a.inv_cnt - mean * mean, 0.f) + a.eps);   // (as gn_params)
       const float s0 = rstd * tb_g[0], s1 = rstd * tb_g[1];
       *(f32x4*)(smem + WS_SCT_OFF + (tidv & 63) * 16) = f32x4{s0, s1, tb_b[0] - mean * s0, tb_b[1] - mean * s1};
     }

@@ -177,6 +177,7 @@ __device__ __forceinline__ void gn_params(const float* sfl, const float* __restr
   if ((cpg & (cpg - 1)) == 0) {   // wave-uniform
     const int g0 = ch0 >> __builtin_ctz(cpg);
     if (cpg >= NCH) gn_params_groups<NCH, NCH>(sfl, gamma, beta, ch0, g0, inv_cnt, eps, sc, sh, mu, rs);
+    else if (NCH > 4 && cpg == 4) gn_params_groups<NCH, (NCH > 4 ? 4 : NCH)>(sfl, gamma, beta, ch0, g0, inv_cnt, eps, sc, sh, mu, rs);
     else if (cpg == 2) gn_params_groups<NCH, 2>(sfl, gamma, beta, ch0, g0, inv_cnt, eps, sc, sh, mu, rs);
     else gn_params_groups<NCH, 1>(sfl, gamma, beta, ch0, g0, inv_cnt, eps, sc, sh, mu, rs);
   } else {

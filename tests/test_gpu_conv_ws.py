@@ -45,7 +45,7 @@ def _same(ref, outs, what, prologue=False):
     """No prologue: bit for bit.  With the GroupNorm prologue the two kernels derive scale / shift in separately compiled code
     (under -ffast-math the FMA contraction of var = E[x^2] - mean^2 and of the affine may differ): rstd / scale can differ by
     one ulp, which flips the 16-bit rounding of a few activations and through them of a few hundred outputs -- each by one
-    ulp of its format.  Allowed: <= 5e-4 of the elements, each within 2^-8 of the tensor's scale."""
+    ulp of its format.  Allowed: <= 2e-3 of the elements, each within 2^-8 of the tensor's scale."""
     for o in outs:
         for k, (a, b) in enumerate(zip(ref, o)):
             if a is None:
@@ -58,7 +58,7 @@ def _same(ref, outs, what, prologue=False):
             if a.dtype in (torch.int64, torch.float32):      # statistics / GroupNorm-backward sums: long sums of slightly different terms
                 assert d.max().item() <= 2e-4 * scale, f"{what}: output {k}: max |diff| {d.max().item():.3e} (scale {scale:.3e})"
                 continue
-            assert nbad <= max(8, 5e-4 * d.numel()), f"{what}: output {k}: {nbad} of {d.numel()} elements differ"
+            assert nbad <= max(8, 2e-3 * d.numel()), f"{what}: output {k}: {nbad} of {d.numel()} elements differ"
             assert d.max().item() <= 2.0 ** -8 * scale, f"{what}: output {k}: max |diff| {d.max().item():.3e} (scale {scale:.3e})"
 
 
