@@ -66,6 +66,15 @@ __device__ __forceinline__ void ws_for(std::integer_sequence<int, I...>, F&& f) 
 
 struct Tile { int n, oy0, ox0, ty, tx; };
 
+#ifdef WS_STAMPS
+// Diagnostic build only (never the shipped library): s_memtime stamps of workgroup 0 .. 7, wave 0, first 12 tiles:
+// [wg][tile][5] = tile start, MFMA loop start, loop end (before barrier a), after barrier (b), tile end.
+__device__ long long pti_ws_stamps[8 * 12 * 5];
+#define WS_STAMP(k) do { if (blockIdx.x < 8 && tidv == 0 && stamp_tile < 12) pti_ws_stamps[(blockIdx.x * 12 + stamp_tile) * 5 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WS_STAMP(k) do {} while (0)
+#endif
+
 // FM: 1 = fp16 in / residual / out, fp16 MFMA operands (forward); 2 = all bf16 (plain data gradient); 3 = bf16 in / out,
 // fp16 "residual" = GroupNorm input of the fused GroupNorm(+SiLU)-backward epilogue.  PRO: PTI_PRO_NONE / _GN / _GN_SILU.
 template <int FM, int PRO, bool SAVE>
@@ -226,6 +235,8 @@ __global__ __launch_bounds__(256, 1) void conv_ws128_kernel(ConvArgs a, int ntil
   __syncthreads();
   }
 
+  int stamp_tile = 0;
+  (void)stamp_tile;
   for (; t < ntiles; t += gridDim.x) {
     const Tile cur = decode(t);      // (re-derived per tile: carried across the loop the five scalars end up spilled)
     unsigned char* hcur = smem + buf * WS_HALO;
@@ -240,6 +251,7 @@ __global__ __launch_bounds__(256, 1) void conv_ws128_kernel(ConvArgs a, int ntil
     asm volatile("" : "+v"(lc), "+v"(lp0), "+v"(pb), "+v"(tk[0]), "+v"(tk[1]), "+v"(tk[2]), "+v"(epc), "+v"(epp0), "+v"(tidv), "+v"(lanev));
     const int hsel = lanev >> 5, j = lanev & 31;      // (shadow the kernel-scope copies inside the tile loop)
 
+    WS_STAMP(0);
     // ---- tile start: residual tile by LDS-DMA, per-tile tables, next tile's loads ----
     reinterpret_cast<float*>(smem + WS_STAT_OFF)[tidv] = 0.f;
     if constexpr (gn_on) {
@@ -311,6 +323,7 @@ __global__ __launch_bounds__(256, 1) void conv_ws128_kernel(ConvArgs a, int ntil
 #pragma unroll
       for (int i = 0; i < 4; ++i) dst[i] = *(const bf16x8*)(bp + 2 * i * 18 * 256);
     };
+    WS_STAMP(1);
     bread(b0, 0);
     __builtin_amdgcn_sched_barrier(0);
     // one k-block: the B reads of the NEXT k-block, 4 MFMAs, and this k-block's share of the staging / side-output work,
@@ -357,6 +370,7 @@ __global__ __launch_bounds__(256, 1) void conv_ws128_kernel(ConvArgs a, int ntil
     unsigned char* etile = smem + WS_ET_OFF;
     const bool do_stats = (FM == 2 || FM == 3) ? false : a.out_stats != nullptr;
     const int ocpg = do_stats ? 128 / a.out_groups : 1;
+    WS_STAMP(2);
     __syncthreads();   // (a) every wave is done with hcur; the next halo and the residual tile are complete
     const unsigned char* rtile = smem + WS_RT_OFF;
     const int col0 = wn * 32 + 4 * hsel;
@@ -481,6 +495,7 @@ __global__ __launch_bounds__(256, 1) void conv_ws128_kernel(ConvArgs a, int ntil
       }
     }
     __syncthreads();   // (b) the output tile (and the group sums) are complete
+    WS_STAMP(3);
     if ((FM == 2) && a.pool2) {
       // data gradient of conv(nearest-2x(x)): store the 2x2-sum-pooled tile (see conv_mfma2_kernel)
 #pragma unroll
@@ -528,6 +543,8 @@ __global__ __launch_bounds__(256, 1) void conv_ws128_kernel(ConvArgs a, int ntil
         atomicAdd((unsigned long long*)&a.out_stats[(n * a.out_groups) * 2 + tidv], (unsigned long long)sstat[tidv]);
     }
     __syncthreads();   // (c) etile / tables are free for the next tile
+    WS_STAMP(4);
+    ++stamp_tile;
     buf ^= 1;
   }
 }
@@ -596,6 +613,12 @@ int launch_conv_ws128(const ConvArgs& a0, hipStream_t st) {
   return 1;
 }
 
+#ifdef WS_STAMPS
+extern "C" int pti_debug_ws_stamps(long long* dst_host) {
+  return (int)hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(pti_ws_stamps), sizeof(long long) * 8 * 12 * 5, 0, hipMemcpyDeviceToHost);
+}
+#endif
+
 }  // namespace pti_conv
 
 // ---- what was measured (round 3, MI355X, batch 32, tools/bench_conv_ws.py: interleaved A/B in one process) --------------
@@ -618,6 +641,18 @@ int launch_conv_ws128(const ConvArgs& a0, hipStream_t st) {
 // B reads / MFMAs / one dword slice of staging per k-block pinned with sched_group_barrier + sched_barrier, the slices
 // anchored with an opaque asm (IR passes otherwise sink them to the LDS write), per-tile laundering of the per-thread
 // address seeds (LICM otherwise hoists ~60 addresses into registers that do not exist).
-// What would make it win: fewer VALU instructions per tile (packed-fp16 SiLU halves the transform but costs forward
+// In-kernel stamps (diagnostic build -DWS_STAMPS + tools/ws_stamps.py; 128^2, 16 tiles per workgroup, cycles per tile of
+// wave 0, medians; 9,216 = the 288 MFMAs alone):
+//                 tile start   MFMA loop   barrier + epilogue   stores    whole tile
+//   fwd plain        1,256       11,960          4,028           1,244      18,480
+//   fwd GN+SiLU      1,292       17,056          4,012           1,228      23,572
+//   fwd full         2,280       18,308          8,952           1,412      31,072
+//   dgrad + GN bwd   2,864       11,852         10,212           1,296      26,240
+// i.e. the pinned loop alone runs at 77 % MFMA-busy, the 816 staging VALU instructions ADD 5,100 cycles to it (6 cycles
+// each: not hidden at all -- the wave issues in order, so every stall of the dependent v_exp -> v_add -> v_rcp -> v_mul
+// chain of a slice also holds back the MFMA behind it), and the epilogue is 4-10 k cycles of exposed, dependency-bound
+// VALU work.  A second wave per SIMD is what hides exactly these stalls in the v2 kernel.
+// What would make it win: the slice chains modulo-scheduled over three k-blocks (exp of dword d, rcp of d-1, pack of d-2 per
+// k-block: no dependent pair inside a k-block), fewer VALU instructions per tile (packed-fp16 SiLU halves the transform but costs forward
 // accuracy: not taken), and the epilogue of tile t interleaved into the MFMAs of tile t+1 (needs a second accumulator
 // set: 64 registers the weight-stationary layout does not have).  Not pursued further this round.
