@@ -122,7 +122,7 @@ def _pmc():
     return pmc
 
 
-CONV3X3 = "conv_mfma2_kernel+conv_ws128_kernel"   # the MFMA conv: v2 kernel + its weight-stationary sibling for 128 -> 128
+CONV3X3 = "conv_mfma2_kernel"   # the MFMA conv family; launches of its experimental sibling conv_ws128_kernel (PTI_CONV_WS=1) fold into it, see "parts"
 
 
 def family(name):
