@@ -1145,6 +1145,225 @@ __global__ __launch_bounds__(256, 1) void wgrad_mfma5_kernel(W4Batch b) {
 #undef AC
 }
 
+// =============================================================================================
+// v6 (round 3): jobs with Cout % 128 == 0 and Cin % 64 == 0.  One workgroup = a 128co x 64ci block of one pixel split;
+// its EIGHT waves (two per SIMD) are eight 32co x 32ci blocks -- wave w8: output-channel block w8 & 3, input-channel half
+// w8 >> 2 -- and every wave multiplies ALL pixels of a tile for all nine taps (9 accumulators = 144 registers).  Against
+// v4's split (waves = pixel rows of ONE or TWO blocks):
+//   * no cross-wave reduction at the end (v4: three rounds through LDS; v5: 288 registers per wave): a wave stores its
+//     nine accumulators straight into the slab;
+//   * a stage (tile of 4 x 16 pixels) is 14 KiB of x halo (6 x 18 pixels x 64 channels) + 16 KiB of dy (64 pixels x 128
+//     channels) = 30 KiB for 8 x 36 = 288 MFMAs: 107 B per MFMA against 199 B in the two-block mode and 284 B in the
+//     pair mode;
+//   * 44 transposing reads per 36 MFMAs per wave (v4: 56 per 18), and the per-tile fixed part (counted wait, barrier,
+//     first fragments) is paid once per 36 MFMAs per wave instead of once per 18;
+//   * the barrier runs one tile ahead and the first fragments of tile it+1 are read at the end of tile it (as v5).
+// Stage image: [x: 2 halves x 7 KiB: [halo pixel (6 x 18, 108 used of 112)][32 ci]][dy: 4 blocks x 4 KiB: [pixel (4 x
+// 16)][32 co]] -- every sub-image is the plain [pixel][32 channels] layout the transposing reads of v4 address.  30 DMA
+// instructions per stage = 4 per wave (two dummies read the zero page into a 1-KiB sink), ring of four stages, three
+// tiles ahead.  Slab format = v4's (block cc32 = (4*cot4 + cb) * (Cin/32) + 2*cit2 + ch), same reduction kernel.
+// =============================================================================================
+constexpr int W6_TH = 4, W6_HW = TW + 2, W6_NPX = (W6_TH + 2) * W6_HW, W6_XSUB = 7 * 1024, W6_XB = 2 * W6_XSUB,
+              W6_DSUB = 4 * 1024, W6_STG = W6_XB + 4 * W6_DSUB, W6_DP = 3, W6_NST = W6_DP + 1, W6_SINK = W6_NST * W6_STG,
+              W6_LDS = W6_SINK + 1024;
+static_assert(W6_LDS <= 160 * 1024 && 4 * (W6_DP - 1) <= 63 && W6_NPX <= 112, "v6 ring");
+
+__global__ __launch_bounds__(512, 1) void wgrad_mfma6_kernel(W4Batch b) {
+  constexpr int PP = 64;
+  const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
+  const int ng = b.ngrp[xcd];
+  if (ng == 0 || pos >= b.grp_start[xcd][ng]) return;
+  int gi = 0;
+  while (gi + 1 < ng && pos >= b.grp_start[xcd][gi + 1]) ++gi;
+  const unsigned gword = b.grp[xcd][gi];
+  const int jb = gword & 15, split = gword >> 4, cc = pos - b.grp_start[xcd][gi];
+  const W4Job& a = b.job[jb];
+  const int ci_pairs = a.Cin / 64;
+  typedef short v4s __attribute__((ext_vector_type(4)));
+  typedef short v8s __attribute__((ext_vector_type(8)));
+  __shared__ __attribute__((aligned(16))) unsigned char smem[W6_LDS];
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cb = w8 & 3, ch = w8 >> 2;
+  const int cot4 = cc / ci_pairs, cit2 = cc % ci_pairs;
+  const int co0 = cot4 * 128, ci0 = cit2 * 64;
+  const bool do_bias = (cit2 == 0) && (ch == 0);     // wave-uniform
+
+  // ---- DMA slots of this wave: instructions w8, w8 + 8, w8 + 16, w8 + 24 of the stage's 32 (0..13 x, 14..29 dy, 30..31 sink) ----
+  int kind[4], ldsoff[4];          // wave-uniform
+  int yy[4], xx[4], rel[4];        // per lane
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int sidx = w8 + 8 * k;
+    const int pix = lane >> 2, piece = lane & 3;
+    if (sidx < 14) {
+      const int h = sidx >= 7 ? 1 : 0, i = sidx - 7 * h, p = 16 * i + pix;
+      kind[k] = 0;
+      ldsoff[k] = h * W6_XSUB + i * 1024;
+      yy[k] = p < W6_NPX ? p / W6_HW : 1 << 20;
+      xx[k] = p - (p / W6_HW) * W6_HW;
+      rel[k] = ((yy[k] - 1) * a.W + xx[k] - 1) * a.Cin * 2 + (ci0 + h * 32 + piece * 8) * 2;
+    } else if (sidx < 30) {
+      const int c = (sidx - 14) >> 2, i = (sidx - 14) & 3;
+      kind[k] = 1;
+      ldsoff[k] = W6_XB + c * W6_DSUB + i * 1024;
+      yy[k] = i;
+      xx[k] = pix;
+      rel[k] = (i * a.W + pix) * a.Cout * 2 + (co0 + c * 32 + piece * 8) * 2;
+    } else {
+      kind[k] = 2;
+      ldsoff[k] = 0;
+      yy[k] = xx[k] = rel[k] = 0;
+    }
+    kind[k] = __builtin_amdgcn_readfirstlane(kind[k]);
+    ldsoff[k] = __builtin_amdgcn_readfirstlane(ldsoff[k]);
+  }
+  const unsigned char* xb = reinterpret_cast<const unsigned char*>(a.x);
+  const unsigned char* db = reinterpret_cast<const unsigned char*>(a.dy);
+  const unsigned char* zero = reinterpret_cast<const unsigned char*>(pti_wgrad_zero_page);
+  struct TilePos { const unsigned char* xt; const unsigned char* dt; int oy0, ox0; bool live, interior; };
+  auto locate = [&](int tile) -> TilePos {
+    TilePos tp;
+    tp.live = tile < a.ntiles;
+    int t = tp.live ? tile : 0;
+    const int tx_ = t % a.tiles_x; t /= a.tiles_x;
+    const int ty_ = t % a.tiles_y;
+    const int n = t / a.tiles_y;
+    tp.oy0 = ty_ * W6_TH; tp.ox0 = tx_ * TW;
+    tp.xt = xb + ((size_t)(n * a.H + tp.oy0) * a.W + tp.ox0) * a.Cin * 2;
+    tp.dt = db + ((size_t)(n * a.H + tp.oy0) * a.W + tp.ox0) * a.Cout * 2;
+    tp.interior = tp.oy0 >= 1 && tp.ox0 >= 1 && tp.oy0 + W6_TH + 1 <= a.H && tp.ox0 + 17 <= a.W;
+    return tp;
+  };
+  auto issue_slot = [&](const TilePos& tp, int stage, int k) {     // k is a compile-time constant at every call site
+    const unsigned sb = __builtin_amdgcn_readfirstlane(lds0 + stage * W6_STG + ldsoff[k]);   // (wave-uniform: M0)
+    if (kind[k] == 0) {
+      bool ok = tp.live && yy[k] < 16;
+      if (!tp.interior) {
+        const int vy = tp.oy0 - 1 + yy[k], vx = tp.ox0 - 1 + xx[k];
+        ok = ok && vy >= 0 && vy < a.H && vx >= 0 && vx < a.W;
+      }
+      glds16(ok ? tp.xt + rel[k] : zero, sb);
+    } else if (kind[k] == 1) {
+      bool ok = tp.live;
+      if (!tp.interior) ok = ok && tp.oy0 + yy[k] < a.H && tp.ox0 + xx[k] < a.W;
+      glds16(ok ? tp.dt + rel[k] : zero, sb);
+    } else {
+      glds16(zero, __builtin_amdgcn_readfirstlane(lds0 + W6_SINK));
+    }
+  };
+
+  f32x16 acc[3][3];
+  float bsum = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) acc[kh][kw][r] = 0.f;
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const int fbase = (8 * (g >> 1) + q) * PP + (16 * (g & 1) + 4 * pp) * 2;   // transposed-read lane base (as v3 / v4)
+  auto tr_frag = [&](const unsigned char* p) -> bf16x8 {
+    const v4s d0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(p));
+    const v4s d1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(p + 4 * PP));
+    const v8s t = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+    return __builtin_bit_cast(bf16x8, t);
+  };
+
+  const int ntl = a.ntiles > split ? (a.ntiles - split + a.S - 1) / a.S : 0;
+  auto tile_of = [&](int k) { return k < ntl ? split + k * a.S : a.ntiles; };   // (past the end: zeros)
+#pragma unroll
+  for (int s = 0; s < W6_DP; ++s) {
+    const TilePos tp = locate(tile_of(s));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) issue_slot(tp, s, k);
+  }
+  // first fragments of a tile: its four dy fragments (output rows 0..3 of this wave's output-channel block) and the x
+  // fragments 0, 1 (halo row 0, kw 0 and 1) of this wave's input-channel half
+  bf16x8 dfr[4], xcur, xq1;
+  auto xfrag_at = [&](const unsigned char* lX, int f) { return tr_frag(lX + fbase + ((f / 3) * W6_HW + f % 3) * PP); };
+  auto first_frags = [&](int slot) {
+    const unsigned char* lS = smem + slot * W6_STG;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dfr[r] = tr_frag(lS + W6_XB + cb * W6_DSUB + fbase + r * TW * PP);
+    xcur = xfrag_at(lS + ch * W6_XSUB, 0);
+    xq1 = xfrag_at(lS + ch * W6_XSUB, 1);
+  };
+  wait_vmcnt<4 * (W6_DP - 1)>();        // tile 0 has landed (this wave's pieces) ...
+  __builtin_amdgcn_s_barrier();         // ... and everyone's
+  first_frags(0);
+
+  int ps = 0;
+  for (int it = 0; it < ntl; ++it) {
+    int fs = ps + W6_DP;
+    fs = fs >= W6_NST ? fs - W6_NST : fs;
+    const int ns = ps + 1 == W6_NST ? 0 : ps + 1;
+    const TilePos ft = locate(tile_of(it + W6_DP));
+    // tile it+1 has landed for every wave (tile it+2 may fly); every wave is also done reading tile it-1's slot, which
+    // this iteration refills with tile it+DP
+    wait_vmcnt<4 * (W6_DP - 2)>();
+    __builtin_amdgcn_s_barrier();
+    const unsigned char* lX = smem + ps * W6_STG + ch * W6_XSUB;
+    if (do_bias) {      // a lane of a dy fragment holds 8 pixels of ONE output channel
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const u32x4 dwv = __builtin_bit_cast(u32x4, dfr[r]);
+        float s8 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s8 += __uint_as_float(dwv[i] << 16) + __uint_as_float(dwv[i] & 0xffff0000u);
+        bsum += s8;
+      }
+    }
+    // 18 x fragments: halo rows 0..5 (rr) x kw; fragment f+2 is read while fragment f's MFMAs issue
+#pragma unroll
+    for (int f = 0; f < 18; ++f) {
+      const int rr = f / 3, kw = f % 3;
+      bf16x8 xq2 = xq1;
+      if (f + 2 < 18) xq2 = xfrag_at(lX, f + 2);
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int r = rr - kh;          // halo row rr = output row r + kh
+        if (r >= 0 && r < 4) acc[kh][kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfr[r], xcur, acc[kh][kw], 0, 0, 0);
+      }
+      if (f == 2) issue_slot(ft, fs, 0);
+      if (f == 6) issue_slot(ft, fs, 1);
+      if (f == 10) issue_slot(ft, fs, 2);
+      if (f == 14) issue_slot(ft, fs, 3);
+      if (f + 2 < 18) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      {
+        const int nm = (rr == 0 || rr == 5) ? 1 : ((rr == 1 || rr == 4) ? 2 : 3);
+        if (nm == 3) __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        else if (nm == 2) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        else __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      xcur = xq1;
+      xq1 = xq2;
+    }
+    first_frags(ns);                     // tile it+1 (its slot was confirmed by this iteration's barrier)
+    ps = ns;
+  }
+  wait_vmcnt<0>();                       // the zero-page pieces of the tiles past the end
+
+  // ---- every wave owns its 32co x 32ci x 9 block outright: store it in the slab's block order ----
+  const int ci = lane & 31, hsel = lane >> 5;
+  const int cc32 = (4 * cot4 + cb) * (a.Cin / 32) + 2 * cit2 + ch;
+  float* blk = a.slab + (size_t)split * a.slab_stride + (size_t)cc32 * 9216;
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4)
+        *(f32x4*)(blk + (kh * 3 + kw) * 1024 + ci * 32 + (((2 * q4 + hsel) ^ (ci & 7)) << 2)) =
+            f32x4{acc[kh][kw][4 * q4], acc[kh][kw][4 * q4 + 1], acc[kh][kw][4 * q4 + 2], acc[kh][kw][4 * q4 + 3]};
+  if (do_bias) {       // lanes l and l + 32 hold the two pixel halves of output channel l
+    const float t = bsum + __shfl_xor(bsum, 32, 64);
+    if (lane < 32) a.slab[(size_t)split * a.slab_stride + (size_t)9 * a.Cout * a.Cin + co0 + cb * 32 + lane] = t;
+  }
+}
+
 // Slab reduction of the v4 layout: slab s = [(co,ci) block cc][tap][ci][co quad ^ (ci & 7)][4 co] + Cout bias sums.
 // Same fixed-order scheme as wgrad_reduce_kernel (16 float4 columns x 16 slab groups per block).
 __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(W4Batch b) {
@@ -1253,14 +1472,21 @@ void launch_wt(const WgArgs& a, int co_t, int ci_t, int grid_y, hipStream_t st) 
 }  // namespace
 
 // ---- v4 batch planning (host) -------------------------------------------------------------------------------------
-static void w4_fill_job(W4Job& a, const void* x, const void* dy, int n, int h, int w, int cin, int cout) {
+// Kernel mode of a job (W4Job::cob2): 0 = pairs of tiles, 32co x 32ci per workgroup; 1 = two output-channel blocks per
+// workgroup (Cout % 64 == 0); 2 = the v6 kernel, 128co x 64ci per workgroup on 4 x 16-pixel tiles (Cout % 128 == 0 and
+// Cin % 64 == 0; PTI_WGRAD_V6=1, read per call: the A/B tool toggles it inside one process).
+static bool w6_wanted(int cin, int cout) {
+  const char* e = getenv("PTI_WGRAD_V6");
+  return e && atoi(e) != 0 && cout % 128 == 0 && cin % 64 == 0;
+}
+static void w4_fill_job(W4Job& a, const void* x, const void* dy, int n, int h, int w, int cin, int cout, bool v6 = false) {
   a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.slab = nullptr;
   a.N = n; a.H = h; a.W = w; a.Cin = cin; a.Cout = cout;
-  a.tiles_x = cdiv(w, TW); a.tiles_y = cdiv(h, TH); a.ntiles = n * a.tiles_x * a.tiles_y;
+  a.tiles_x = cdiv(w, TW); a.tiles_y = cdiv(h, v6 ? W6_TH : TH); a.ntiles = n * a.tiles_x * a.tiles_y;
   a.slab_stride = (long long)9 * cout * cin + cout;
   a.S = 1;
   static const int cob2_env = getenv("PTI_WGRAD_V4_COB2") ? atoi(getenv("PTI_WGRAD_V4_COB2")) : 1;
-  a.cob2 = (cob2_env && cout % 64 == 0) ? 1 : 0;
+  a.cob2 = v6 ? 2 : ((cob2_env && cout % 64 == 0) ? 1 : 0);
 }
 static bool w4_eligible(int n, int h, int w, int cin, int cout) {
   return n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && cin % 32 == 0 && cout % 32 == 0 &&
@@ -1290,10 +1516,18 @@ static long long w4_plan(W4Batch& b, float* workspace, long long workspace_float
   static const int diag_env = wgrad_diag_env();
   b.diag = diag_env;
   // workgroups of one pixel split: (co, ci) blocks of 32 x 32, or of 64 x 32 in the two-block mode
-  auto tiles32 = [](const W4Job& a) { return (a.Cin / 32) * (a.Cout / (a.cob2 ? 64 : 32)); };
+  auto tiles32 = [](const W4Job& a) {
+    return a.cob2 == 2 ? (a.Cin / 64) * (a.Cout / 128) : (a.Cin / 32) * (a.Cout / (a.cob2 ? 64 : 32));
+  };
+  // v6 batches (every job in mode 2): a workgroup writes EIGHT 37-KB blocks, so the launch aims at fewer, longer
+  // workgroups (PTI_WGRAD_V6_WGS, default 512 = two rounds per CU); work is counted in workgroup-tiles
+  const bool m6 = b.njobs > 0 && b.job[0].cob2 == 2;
+  const char* w6e = getenv("PTI_WGRAD_V6_WGS");
+  const int wgs6 = w6e && atoi(w6e) > 0 ? atoi(w6e) : 512;
   double work = 0;   // 32 x 32-block tiles of the whole launch (a two-block workgroup does two per pixel tile)
-  for (int j = 0; j < b.njobs; ++j) work += (double)tiles32(b.job[j]) * (b.job[j].cob2 ? 2 : 1) * b.job[j].ntiles;
+  for (int j = 0; j < b.njobs; ++j) work += (double)tiles32(b.job[j]) * (b.job[j].cob2 == 1 ? 2 : 1) * b.job[j].ntiles;
   double per_wg = work / wgs_env > 2.0 ? work / wgs_env : 2.0;   // tiles per workgroup aimed at (at least one pair)
+  if (m6) per_wg = work / wgs6 > 4.0 ? work / wgs6 : 4.0;
   for (int attempt = 0;; ++attempt) {
     long long used = 0;
     int rb = 0, groups = 0;
@@ -1302,7 +1536,7 @@ static long long w4_plan(W4Batch& b, float* workspace, long long workspace_float
       W4Job& a = b.job[j];
       // per_wg = pixel tiles per workgroup in the pair mode (two per iteration); a two-block workgroup takes one pixel
       // tile per iteration, so the same running time is per_wg / 2 pixel tiles: twice the splits
-      int S = (int)((double)a.ntiles * (a.cob2 ? 2 : 1) / per_wg + 0.5);
+      int S = (int)((double)a.ntiles * (a.cob2 == 1 ? 2 : 1) / per_wg + 0.5);
       if (S > a.ntiles / (a.cob2 ? 1 : 2)) S = a.ntiles / (a.cob2 ? 1 : 2);
       if (S > 255) S = 255;
       if (S < 1) S = 1;
@@ -1423,14 +1657,15 @@ extern "C" int pti_conv_wgrad_mfma_partials(const void* x, const void* dy, const
   if (v4) {
     W4Batch b;
     b.njobs = 1;
-    w4_fill_job(b.job[0], x, dy, d->n, d->h, d->w, d->cin, d->cout);
+    w4_fill_job(b.job[0], x, dy, d->n, d->h, d->w, d->cin, d->cout, w6_wanted(d->cin, d->cout) && !diag_env);
     b.dw[0] = b.dbias[0] = nullptr;
     b.accumulate[0] = 0;
     if (w4_plan(b, (float*)workspace, workspace_bytes / 4) < 0)
       PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma: workspace too small (%lld bytes per split needed)", a.slab_stride * 4);
     const char* v5e = getenv("PTI_WGRAD_V5");     // (read per call here: the A/B tool toggles it inside one process)
     const bool v5 = v5e && atoi(v5e) != 0 && !b.diag;
-    if (b.job[0].cob2 && v5) PTI_LAUNCH(wgrad_mfma5_kernel, dim3(b.nwg), dim3(256), 0, (hipStream_t)s, b);
+    if (b.job[0].cob2 == 2) PTI_LAUNCH(wgrad_mfma6_kernel, dim3(b.nwg), dim3(512), 0, (hipStream_t)s, b);
+    else if (b.job[0].cob2 && v5) PTI_LAUNCH(wgrad_mfma5_kernel, dim3(b.nwg), dim3(256), 0, (hipStream_t)s, b);
     else if (b.job[0].cob2) PTI_LAUNCH(wgrad_mfma4_kernel<true>, dim3(b.nwg), dim3(512), 0, (hipStream_t)s, b);
     else PTI_LAUNCH(wgrad_mfma4_kernel<false>, dim3(b.nwg), dim3(512), 0, (hipStream_t)s, b);
     PTI_CHECK_LAUNCH("conv_wgrad_mfma");
@@ -1490,10 +1725,10 @@ extern "C" int pti_conv_wgrad_mfma_batched(const pti_wgrad_job* jobs, int njobs,
                                            pti_stream_t s) {
   if (!jobs || !workspace || njobs < 1 || njobs > PTI_WGRAD_BATCH_MAX)
     PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma_batched: 1..%d jobs", PTI_WGRAD_BATCH_MAX);
-  // two batches, one per kernel mode (two output-channel blocks per workgroup for Cout % 64 == 0, pairs of tiles
-  // otherwise); each gets its own launch pair and its own part of the workspace
-  W4Batch bm[2];
-  bm[0].njobs = bm[1].njobs = 0;
+  // one batch per kernel mode (see w4_fill_job); each gets its own launch pair and its own part of the workspace
+  W4Batch bm[3];
+  bm[0].njobs = bm[1].njobs = bm[2].njobs = 0;
+  static const int diag_env = wgrad_diag_env();
   for (int j = 0; j < njobs; ++j) {
     const pti_wgrad_job& q = jobs[j];
     if (!q.x || !q.dy || !q.dw) PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma_batched: job %d has a null pointer", j);
@@ -1501,41 +1736,40 @@ extern "C" int pti_conv_wgrad_mfma_batched(const pti_wgrad_job* jobs, int njobs,
       PTI_FAIL(PTI_EUNSUPPORTED, "conv_wgrad_mfma_batched: job %d: n=%d h=%d w=%d cin=%d cout=%d (channels must be multiples of 32, tensors < 2 GiB)",
                j, q.n, q.h, q.w, q.cin, q.cout);
     W4Job jb;
-    w4_fill_job(jb, q.x, q.dy, q.n, q.h, q.w, q.cin, q.cout);
-    W4Batch& b = bm[jb.cob2 ? 1 : 0];
+    w4_fill_job(jb, q.x, q.dy, q.n, q.h, q.w, q.cin, q.cout, w6_wanted(q.cin, q.cout) && !diag_env);
+    W4Batch& b = bm[jb.cob2];
     const int k = b.njobs++;
     b.job[k] = jb;
     b.dw[k] = q.dw; b.dbias[k] = q.dbias; b.accumulate[k] = q.accumulate;
   }
   float* ws = (float*)workspace;
   long long ws_floats = workspace_bytes / 4;
-  for (int m = 1; m >= 0; --m) {      // the two-block batch first (it is the larger one on every model of the reference)
+  const char* v5e = getenv("PTI_WGRAD_V5");
+  const int v5_env = v5e ? atoi(v5e) : 0;
+  const void* main_kernel = nullptr;
+  for (int m = 2; m >= 0; --m) {      // the widest blocks first (they are the larger batches on every model of the reference)
     W4Batch& b = bm[m];
     if (b.njobs == 0) continue;
-    // when both modes are present the first batch may take at most 3/4 of the workspace
-    const long long avail = (m == 1 && bm[0].njobs > 0) ? ws_floats * 3 / 4 : ws_floats;
+    // a batch that is followed by another one may take at most 3/4 of what is left of the workspace
+    bool more = false;
+    for (int m2 = m - 1; m2 >= 0; --m2) more = more || bm[m2].njobs > 0;
+    const long long avail = more ? ws_floats * 3 / 4 : ws_floats;
     const long long used = w4_plan(b, ws, avail);
     if (used < 0) PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma_batched: workspace too small");
     ws += used;
     ws_floats -= used;
     // two-block jobs: PTI_WGRAD_V5=1 selects the one-wave-per-SIMD kernel (v5; bit-identical results, measured 15-48 %
     // SLOWER than v4 in round 3 -- see the note above wgrad_mfma5_kernel -- hence off by default)
-    const char* v5e = getenv("PTI_WGRAD_V5");
-    const int v5_env = v5e ? atoi(v5e) : 0;
-    if (m == 1 && v5_env && !b.diag) PTI_LAUNCH(wgrad_mfma5_kernel, dim3(b.nwg), dim3(256), 0, (hipStream_t)s, b);
-    else if (m == 1) PTI_LAUNCH(wgrad_mfma4_kernel<true>, dim3(b.nwg), dim3(512), 0, (hipStream_t)s, b);
-    else PTI_LAUNCH(wgrad_mfma4_kernel<false>, dim3(b.nwg), dim3(512), 0, (hipStream_t)s, b);
+    const void* kfn;
+    if (m == 2) { PTI_LAUNCH(wgrad_mfma6_kernel, dim3(b.nwg), dim3(512), 0, (hipStream_t)s, b); kfn = reinterpret_cast<const void*>(wgrad_mfma6_kernel); }
+    else if (m == 1 && v5_env && !b.diag) { PTI_LAUNCH(wgrad_mfma5_kernel, dim3(b.nwg), dim3(256), 0, (hipStream_t)s, b); kfn = reinterpret_cast<const void*>(wgrad_mfma5_kernel); }
+    else if (m == 1) { PTI_LAUNCH(wgrad_mfma4_kernel<true>, dim3(b.nwg), dim3(512), 0, (hipStream_t)s, b); kfn = reinterpret_cast<const void*>(wgrad_mfma4_kernel<true>); }
+    else { PTI_LAUNCH(wgrad_mfma4_kernel<false>, dim3(b.nwg), dim3(512), 0, (hipStream_t)s, b); kfn = reinterpret_cast<const void*>(wgrad_mfma4_kernel<false>); }
     PTI_CHECK_LAUNCH("conv_wgrad_mfma_batched");
+    if (!main_kernel) main_kernel = kfn;
     PTI_LAUNCH(wgrad_reduce4_kernel, dim3(b.first_rblk[b.njobs]), dim3(256), 0, (hipStream_t)s, b);
     PTI_CHECK_LAUNCH("conv_wgrad_mfma_batched reduce");
   }
-  // pti_last_kernel_name(): the call's main kernel
-  {
-    const char* v5e2 = getenv("PTI_WGRAD_V5");
-    const int v5_env2 = v5e2 ? atoi(v5e2) : 0;
-    pti_last_kernel = bm[1].njobs ? ((v5_env2 && !bm[1].diag) ? reinterpret_cast<const void*>(wgrad_mfma5_kernel)
-                                                             : reinterpret_cast<const void*>(wgrad_mfma4_kernel<true>))
-                                  : reinterpret_cast<const void*>(wgrad_mfma4_kernel<false>);
-  }
+  pti_last_kernel = main_kernel;      // pti_last_kernel_name(): the call's main kernel
   return PTI_OK;
 }

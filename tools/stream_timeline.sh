@@ -46,5 +46,20 @@ print(f"first wgrad launch at +{(wg[0][0] - t0) / 1e6:.3f} ms, last wgrad ends +
       f"last non-Adam kernel of the main queue ends +{(last_main - t0) / 1e6:.3f} ms")
 for s, e, qq, n in wg:
     print(f"   wgrad {n:24s} q{qq} +{(s - t0) / 1e6:7.3f} .. +{(e - t0) / 1e6:7.3f} ms ({(e - s) / 1e3:7.1f} us)")
+# idle time of the main queue: gaps between consecutive kernels, by (previous -> next) pair, and the whole sequence
+mq = [e for e in step if e[2] == main_q]
+gaps = collections.Counter(); cnt = collections.Counter(); idle = 0
+for a, b in zip(mq, mq[1:]):
+    g = b[0] - a[1]
+    if g > 0:
+        idle += g; gaps[(a[3], b[3])] += g; cnt[(a[3], b[3])] += 1
+print(f"main queue: {len(mq)} launches, idle between kernels {idle / 1e6:.3f} ms")
+for (x, y), v in gaps.most_common(14):
+    print(f"   gap {x:26s} -> {y:26s} n={cnt[(x, y)]:3d} total {v / 1e3:7.1f} us  avg {v / cnt[(x, y)] / 1e3:5.1f} us")
+print("main queue sequence (start ms, duration us, gap before us):")
+prev = None
+for s, e, qq, n in mq:
+    print(f"   +{(s - t0) / 1e6:7.3f} {(e - s) / 1e3:7.1f} {((s - prev) / 1e3 if prev else 0):6.1f}  {n}")
+    prev = e
 PY
 find "$out/t" -name '*.csv' -delete
