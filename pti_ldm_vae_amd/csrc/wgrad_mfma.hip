@@ -1160,12 +1160,12 @@ __global__ __launch_bounds__(256, 1) void wgrad_mfma5_kernel(W4Batch b) {
 //   * the barrier runs one tile ahead and the first fragments of tile it+1 are read at the end of tile it (as v5).
 // Stage image: [x: 2 halves x 7 KiB: [halo pixel (6 x 18, 108 used of 112)][32 ci]][dy: 4 blocks x 4 KiB: [pixel (4 x
 // 16)][32 co]] -- every sub-image is the plain [pixel][32 channels] layout the transposing reads of v4 address.  30 DMA
-// instructions per stage = 4 per wave (two dummies read the zero page into a 1-KiB sink), ring of four stages, three
-// tiles ahead.  Slab format = v4's (block cc32 = (4*cot4 + cb) * (Cin/32) + 2*cit2 + ch), same reduction kernel.
+// instructions per stage = 4 per wave (two dummies read the zero page into the stage's 1-KiB sink), ring of four
+// 31-KiB stages, three tiles ahead.  Slab format = v4's (block cc32 = (4*cot4 + cb) * (Cin/32) + 2*cit2 + ch), same reduction kernel.
 // =============================================================================================
 constexpr int W6_TH = 4, W6_HW = TW + 2, W6_NPX = (W6_TH + 2) * W6_HW, W6_XSUB = 7 * 1024, W6_XB = 2 * W6_XSUB,
-              W6_DSUB = 4 * 1024, W6_STG = W6_XB + 4 * W6_DSUB, W6_DP = 3, W6_NST = W6_DP + 1, W6_SINK = W6_NST * W6_STG,
-              W6_LDS = W6_SINK + 1024;
+              W6_DSUB = 4 * 1024, W6_STG = W6_XB + 4 * W6_DSUB, W6_STGS = W6_STG + 1024 /* + sink */, W6_DP = 3,
+              W6_NST = W6_DP + 1, W6_LDS = W6_NST * W6_STGS;
 static_assert(W6_LDS <= 160 * 1024 && 4 * (W6_DP - 1) <= 63 && W6_NPX <= 112, "v6 ring");
 
 __global__ __launch_bounds__(512, 1) void wgrad_mfma6_kernel(W4Batch b) {
@@ -1190,68 +1190,66 @@ __global__ __launch_bounds__(512, 1) void wgrad_mfma6_kernel(W4Batch b) {
   const int co0 = cot4 * 128, ci0 = cit2 * 64;
   const bool do_bias = (cit2 == 0) && (ch == 0);     // wave-uniform
 
-  // ---- DMA slots of this wave: instructions w8, w8 + 8, w8 + 16, w8 + 24 of the stage's 32 (0..13 x, 14..29 dy, 30..31 sink) ----
-  int kind[4], ldsoff[4];          // wave-uniform
+  // ---- DMA slots of this wave (the kind of slot k is the same for every wave: no branch at the issue site) ----
+  //   k = 0: x instruction w8 (0..7);  k = 1: x instruction 8 + w8 for w8 < 6, else 1 KiB of zeros into the stage's sink;
+  //   k = 2: dy instruction w8;  k = 3: dy instruction 8 + w8.   x instruction xi = 16 halo pixels (x 4 pieces) of
+  //   input-channel half xi / 7; dy instruction di = tile row di & 3 of output-channel block di >> 2.
+  // Per lane: pixel coordinates RELATIVE to the tile origin (halo: -1 ..), the byte offset from the tile's first pixel
+  // and a validity flag; range checks against the image are done for every piece (4 VALU instructions) -- a separate
+  // interior fast path cost more in branches and kernel-argument reloads (s_load + lgkmcnt(0), which also drains the
+  // wave's LDS reads) than it saved.
+  int H = a.H, W = a.W;
+  asm volatile("" : "+s"(H), "+s"(W));          // keep them in SGPRs (otherwise re-read from the kernel arguments per use)
+  int ldsoff[4];                   // wave-uniform
   int yy[4], xx[4], rel[4];        // per lane
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int sidx = w8 + 8 * k;
+  bool pv[4];
+  {
     const int pix = lane >> 2, piece = lane & 3;
-    if (sidx < 14) {
-      const int h = sidx >= 7 ? 1 : 0, i = sidx - 7 * h, p = 16 * i + pix;
-      kind[k] = 0;
-      ldsoff[k] = h * W6_XSUB + i * 1024;
-      yy[k] = p < W6_NPX ? p / W6_HW : 1 << 20;
-      xx[k] = p - (p / W6_HW) * W6_HW;
-      rel[k] = ((yy[k] - 1) * a.W + xx[k] - 1) * a.Cin * 2 + (ci0 + h * 32 + piece * 8) * 2;
-    } else if (sidx < 30) {
-      const int c = (sidx - 14) >> 2, i = (sidx - 14) & 3;
-      kind[k] = 1;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int xi = w8 + 8 * k;
+      const bool sink = xi >= 14;
+      const int h = xi >= 7 ? 1 : 0, i = xi - 7 * h, p = 16 * i + pix;
+      ldsoff[k] = sink ? 4 * W6_DSUB + W6_XB : h * W6_XSUB + i * 1024;
+      pv[k] = !sink && p < W6_NPX;
+      yy[k] = p / W6_HW - 1;
+      xx[k] = p - (p / W6_HW) * W6_HW - 1;
+      rel[k] = (yy[k] * W + xx[k]) * a.Cin * 2 + (ci0 + h * 32 + piece * 8) * 2;
+    }
+#pragma unroll
+    for (int k = 2; k < 4; ++k) {
+      const int di = w8 + 8 * (k - 2), c = di >> 2, i = di & 3;
       ldsoff[k] = W6_XB + c * W6_DSUB + i * 1024;
+      pv[k] = true;
       yy[k] = i;
       xx[k] = pix;
-      rel[k] = (i * a.W + pix) * a.Cout * 2 + (co0 + c * 32 + piece * 8) * 2;
-    } else {
-      kind[k] = 2;
-      ldsoff[k] = 0;
-      yy[k] = xx[k] = rel[k] = 0;
+      rel[k] = (i * W + pix) * a.Cout * 2 + (co0 + c * 32 + piece * 8) * 2;
     }
-    kind[k] = __builtin_amdgcn_readfirstlane(kind[k]);
-    ldsoff[k] = __builtin_amdgcn_readfirstlane(ldsoff[k]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ldsoff[k] = __builtin_amdgcn_readfirstlane(ldsoff[k]);
   }
   const unsigned char* xb = reinterpret_cast<const unsigned char*>(a.x);
   const unsigned char* db = reinterpret_cast<const unsigned char*>(a.dy);
   const unsigned char* zero = reinterpret_cast<const unsigned char*>(pti_wgrad_zero_page);
-  struct TilePos { const unsigned char* xt; const unsigned char* dt; int oy0, ox0; bool live, interior; };
-  auto locate = [&](int tile) -> TilePos {
+  struct TilePos { const unsigned char* xt; const unsigned char* dt; int oy0, ox0; };
+  auto locate = [&](int tile) -> TilePos {       // (wave-uniform; a tile past the end gets an origin outside every image)
     TilePos tp;
-    tp.live = tile < a.ntiles;
-    int t = tp.live ? tile : 0;
+    const bool live = tile < a.ntiles;
+    int t = live ? tile : 0;
     const int tx_ = t % a.tiles_x; t /= a.tiles_x;
     const int ty_ = t % a.tiles_y;
     const int n = t / a.tiles_y;
-    tp.oy0 = ty_ * W6_TH; tp.ox0 = tx_ * TW;
-    tp.xt = xb + ((size_t)(n * a.H + tp.oy0) * a.W + tp.ox0) * a.Cin * 2;
-    tp.dt = db + ((size_t)(n * a.H + tp.oy0) * a.W + tp.ox0) * a.Cout * 2;
-    tp.interior = tp.oy0 >= 1 && tp.ox0 >= 1 && tp.oy0 + W6_TH + 1 <= a.H && tp.ox0 + 17 <= a.W;
+    tp.oy0 = live ? ty_ * W6_TH : 1 << 24; tp.ox0 = tx_ * TW;
+    const size_t pix0 = (size_t)(n * H + ty_ * W6_TH) * W + tp.ox0;
+    tp.xt = xb + pix0 * a.Cin * 2;
+    tp.dt = db + pix0 * a.Cout * 2;
     return tp;
   };
   auto issue_slot = [&](const TilePos& tp, int stage, int k) {     // k is a compile-time constant at every call site
-    const unsigned sb = __builtin_amdgcn_readfirstlane(lds0 + stage * W6_STG + ldsoff[k]);   // (wave-uniform: M0)
-    if (kind[k] == 0) {
-      bool ok = tp.live && yy[k] < 16;
-      if (!tp.interior) {
-        const int vy = tp.oy0 - 1 + yy[k], vx = tp.ox0 - 1 + xx[k];
-        ok = ok && vy >= 0 && vy < a.H && vx >= 0 && vx < a.W;
-      }
-      glds16(ok ? tp.xt + rel[k] : zero, sb);
-    } else if (kind[k] == 1) {
-      bool ok = tp.live;
-      if (!tp.interior) ok = ok && tp.oy0 + yy[k] < a.H && tp.ox0 + xx[k] < a.W;
-      glds16(ok ? tp.dt + rel[k] : zero, sb);
-    } else {
-      glds16(zero, __builtin_amdgcn_readfirstlane(lds0 + W6_SINK));
-    }
+    if (b.diag & 1) return;                                   // tuning aid (wrong results): no tile loads
+    const unsigned sb = __builtin_amdgcn_readfirstlane(lds0 + stage * W6_STGS + ldsoff[k]);   // (wave-uniform: M0)
+    const bool ok = pv[k] && (unsigned)(tp.oy0 + yy[k]) < (unsigned)H && (unsigned)(tp.ox0 + xx[k]) < (unsigned)W;
+    glds16(ok ? (k < 2 ? tp.xt : tp.dt) + rel[k] : zero, sb);
   };
 
   f32x16 acc[3][3];
@@ -1284,7 +1282,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_mfma6_kernel(W4Batch b) {
   bf16x8 dfr[4], xcur, xq1;
   auto xfrag_at = [&](const unsigned char* lX, int f) { return tr_frag(lX + fbase + ((f / 3) * W6_HW + f % 3) * PP); };
   auto first_frags = [&](int slot) {
-    const unsigned char* lS = smem + slot * W6_STG;
+    const unsigned char* lS = smem + slot * W6_STGS;
 #pragma unroll
     for (int r = 0; r < 4; ++r) dfr[r] = tr_frag(lS + W6_XB + cb * W6_DSUB + fbase + r * TW * PP);
     xcur = xfrag_at(lS + ch * W6_XSUB, 0);
@@ -1304,7 +1302,13 @@ __global__ __launch_bounds__(512, 1) void wgrad_mfma6_kernel(W4Batch b) {
     // this iteration refills with tile it+DP
     wait_vmcnt<4 * (W6_DP - 2)>();
     __builtin_amdgcn_s_barrier();
-    const unsigned char* lX = smem + ps * W6_STG + ch * W6_XSUB;
+    const unsigned char* lX = smem + ps * W6_STGS + ch * W6_XSUB;
+    if (b.diag & 2) {                     // tuning aid (wrong results): loads only
+#pragma unroll
+      for (int k = 0; k < 4; ++k) issue_slot(ft, fs, k);
+      ps = ns;
+      continue;
+    }
     if (do_bias) {      // a lane of a dy fragment holds 8 pixels of ONE output channel
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -1657,7 +1661,7 @@ extern "C" int pti_conv_wgrad_mfma_partials(const void* x, const void* dy, const
   if (v4) {
     W4Batch b;
     b.njobs = 1;
-    w4_fill_job(b.job[0], x, dy, d->n, d->h, d->w, d->cin, d->cout, w6_wanted(d->cin, d->cout) && !diag_env);
+    w4_fill_job(b.job[0], x, dy, d->n, d->h, d->w, d->cin, d->cout, w6_wanted(d->cin, d->cout));
     b.dw[0] = b.dbias[0] = nullptr;
     b.accumulate[0] = 0;
     if (w4_plan(b, (float*)workspace, workspace_bytes / 4) < 0)
@@ -1728,7 +1732,6 @@ extern "C" int pti_conv_wgrad_mfma_batched(const pti_wgrad_job* jobs, int njobs,
   // one batch per kernel mode (see w4_fill_job); each gets its own launch pair and its own part of the workspace
   W4Batch bm[3];
   bm[0].njobs = bm[1].njobs = bm[2].njobs = 0;
-  static const int diag_env = wgrad_diag_env();
   for (int j = 0; j < njobs; ++j) {
     const pti_wgrad_job& q = jobs[j];
     if (!q.x || !q.dy || !q.dw) PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma_batched: job %d has a null pointer", j);
@@ -1736,7 +1739,7 @@ extern "C" int pti_conv_wgrad_mfma_batched(const pti_wgrad_job* jobs, int njobs,
       PTI_FAIL(PTI_EUNSUPPORTED, "conv_wgrad_mfma_batched: job %d: n=%d h=%d w=%d cin=%d cout=%d (channels must be multiples of 32, tensors < 2 GiB)",
                j, q.n, q.h, q.w, q.cin, q.cout);
     W4Job jb;
-    w4_fill_job(jb, q.x, q.dy, q.n, q.h, q.w, q.cin, q.cout, w6_wanted(q.cin, q.cout) && !diag_env);
+    w4_fill_job(jb, q.x, q.dy, q.n, q.h, q.w, q.cin, q.cout, w6_wanted(q.cin, q.cout));
     W4Batch& b = bm[jb.cob2];
     const int k = b.njobs++;
     b.job[k] = jb;

@@ -39,7 +39,8 @@ def run(x, dy, v6):
 
 
 # ---- correctness on ragged shapes against torch (fp32 conv of the same bf16 values) ----
-for n, h, w, cin, cout in [(2, 8, 16, 64, 128), (3, 13, 21, 64, 128), (2, 30, 20, 128, 128), (1, 4, 16, 128, 256), (5, 7, 5, 64, 128)]:
+CHECK = os.environ.get("SKIP_CHECK", "0") != "1"      # (skipped under the wrong-result tuning aids)
+for n, h, w, cin, cout in [] if not CHECK else [(2, 8, 16, 64, 128), (3, 13, 21, 64, 128), (2, 30, 20, 128, 128), (1, 4, 16, 128, 256), (5, 7, 5, 64, 128)]:
     g = torch.Generator(device=dev).manual_seed(h * 100 + w)
     x = torch.randn(n, h, w, cin, device=dev, generator=g).bfloat16()
     dy = torch.randn(n, h, w, cout, device=dev, generator=g).bfloat16()
