@@ -1146,30 +1146,50 @@ __global__ __launch_bounds__(256, 1) void wgrad_mfma5_kernel(W4Batch b) {
 }
 
 // =============================================================================================
-// v6 (round 3): jobs with Cout % 128 == 0 and Cin % 64 == 0.  One workgroup = a 128co x 64ci block of one pixel split;
-// its EIGHT waves (two per SIMD) are eight 32co x 32ci blocks -- wave w8: output-channel block w8 & 3, input-channel half
-// w8 >> 2 -- and every wave multiplies ALL pixels of a tile for all nine taps (9 accumulators = 144 registers).  Against
-// v4's split (waves = pixel rows of ONE or TWO blocks):
-//   * no cross-wave reduction at the end (v4: three rounds through LDS; v5: 288 registers per wave): a wave stores its
-//     nine accumulators straight into the slab;
-//   * a stage (tile of 4 x 16 pixels) is 14 KiB of x halo (6 x 18 pixels x 64 channels) + 16 KiB of dy (64 pixels x 128
-//     channels) = 30 KiB for 8 x 36 = 288 MFMAs: 107 B per MFMA against 199 B in the two-block mode and 284 B in the
-//     pair mode;
+// v6 (round 3).  A workgroup's EIGHT waves (two per SIMD) each own a whole 32co x 32ci block: all nine taps (9
+// accumulators = 144 registers) over ALL pixels of the wave's rows of a tile.  Two shapes (template W6Cfg):
+//   A: NCB 4 x NCH 2 x NRG 1 -- 128co x 64ci per workgroup on 4 x 16-pixel tiles (jobs with Cout % 128 == 0, Cin % 64 == 0):
+//      wave w8 = output-channel block w8 & 3, input-channel half w8 >> 2;
+//   B: NCB 2 x NCH 2 x NRG 2 -- 64co x 64ci per workgroup on 8 x 16-pixel tiles (Cout % 64 == 0, Cin % 64 == 0): the two
+//      row groups take output rows 0..3 / 4..7 of the tile and are summed through LDS once, at the end.
+// Against v4's split (eight waves = pixel rows of ONE or TWO blocks):
+//   * no (A) / one (B) cross-wave reduction round at the end (v4: three rounds; v5: 288 registers per wave);
+//   * a stage is 30 KiB (A: 14 KiB of x halo, 6 x 18 pixels x 64 channels + 16 KiB of dy) or 40 KiB (B: 24 + 16) for
+//     8 x 36 = 288 MFMAs: 107 / 142 B per MFMA against 199 B in v4's two-block mode and 284 B in its pair mode;
 //   * 44 transposing reads per 36 MFMAs per wave (v4: 56 per 18), and the per-tile fixed part (counted wait, barrier,
 //     first fragments) is paid once per 36 MFMAs per wave instead of once per 18;
-//   * the barrier runs one tile ahead and the first fragments of tile it+1 are read at the end of tile it (as v5).
-// Stage image: [x: 2 halves x 7 KiB: [halo pixel (6 x 18, 108 used of 112)][32 ci]][dy: 4 blocks x 4 KiB: [pixel (4 x
-// 16)][32 co]] -- every sub-image is the plain [pixel][32 channels] layout the transposing reads of v4 address.  30 DMA
-// instructions per stage = 4 per wave (two dummies read the zero page into the stage's 1-KiB sink), ring of four
-// 31-KiB stages, three tiles ahead.  Slab format = v4's (block cc32 = (4*cot4 + cb) * (Cin/32) + 2*cit2 + ch), same reduction kernel.
+//   * the barrier runs one tile ahead and the first fragments of tile it+1 are read at the end of tile it (as v5);
+//   * the DMA slot logic is branch-free (see the slot table below).
+// Stage image: [x: NCH sub-images [halo pixel ((TH+2) x 18)][32 ci]][dy: NCB sub-images [pixel (TH x 16)][32 co]] --
+// every sub-image is the plain [pixel][32 channels] layout the transposing reads of v4 address.  A: 30 DMA instructions
+// per stage = 4 per wave with two dummies (zero page -> the stage's 1-KiB sink), ring of four stages, three tiles ahead;
+// B: 40 = 5 per wave, ring of three, two ahead.  Slab format = v4's, same reduction kernel.
+// MEASURED (MI355X, batch 32, tools/bench_wgrad_v6.py, interleaved with v4 in one process; identical results run to run,
+// 2e-7 from torch's fp32 weight gradient like v4): shape A 128->128@32^2 53 -> 38 us, @64^2 88 -> 66, @128^2 229 -> 185
+// (675 -> 836 TFLOP/s), 256->256@64^2 225 -> 185; training step (config A, same box) -2.9 %.
 // =============================================================================================
-constexpr int W6_TH = 4, W6_HW = TW + 2, W6_NPX = (W6_TH + 2) * W6_HW, W6_XSUB = 7 * 1024, W6_XB = 2 * W6_XSUB,
-              W6_DSUB = 4 * 1024, W6_STG = W6_XB + 4 * W6_DSUB, W6_STGS = W6_STG + 1024 /* + sink */, W6_DP = 3,
-              W6_NST = W6_DP + 1, W6_LDS = W6_NST * W6_STGS;
-static_assert(W6_LDS <= 160 * 1024 && 4 * (W6_DP - 1) <= 63 && W6_NPX <= 112, "v6 ring");
+template <int NCB_, int NCH_, int NRG_>
+struct W6Cfg {
+  static constexpr int NCB = NCB_, NCH = NCH_, NRG = NRG_, TH_ = 4 * NRG_, HW_ = TW + 2, NPX = (TH_ + 2) * HW_;
+  static constexpr int XI = (NPX + 15) / 16;                 // DMA instructions (16 pixels each) per x sub-image
+  static constexpr int XSUB = XI * 1024, XB = NCH * XSUB, DSUB = TH_ * 1024, STG = XB + NCB * DSUB;
+  static constexpr int NX = NCH * XI, KX = (NX + 7) / 8, ND = NCB * TH_, KD = ND / 8, NSLOT = KX + KD;
+  static constexpr bool SINK = NX % 8 != 0;
+  static constexpr int STGS = STG + (SINK ? 1024 : 0);
+  // B's fold goes through LDS in two rounds (taps 0..4, 5..8): four 20-KiB half blocks + bias partials.  The ring is
+  // kept at <= 124 KiB: a workgroup that takes the whole LDS (v4: 160 KiB) keeps every other kernel off its CU, and the
+  // training step runs the data-gradient chain on the other stream (B with a four-stage 160-KiB ring: +0.2 ms per step)
+  static constexpr int FOLD = NRG == 2 ? NCB * NCH * 5 * 1024 * 4 + 1024 : 0;
+  static constexpr int NST = (124 * 1024) / STGS >= 4 ? 4 : 3, DP = NST - 1;
+  static constexpr int LDS = NST * STGS > FOLD ? NST * STGS : FOLD;
+  static_assert(NCB * NCH * NRG == 8 && ND % 8 == 0 && LDS <= 160 * 1024 && NSLOT * (DP - 1) <= 63, "v6 shape");
+};
+using W6A = W6Cfg<4, 2, 1>;
+using W6B = W6Cfg<2, 2, 2>;
 
+template <class C>
 __global__ __launch_bounds__(512, 1) void wgrad_mfma6_kernel(W4Batch b) {
-  constexpr int PP = 64;
+  constexpr int PP = 64, HWp = C::HW_;
   const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
   const int ng = b.ngrp[xcd];
   if (ng == 0 || pos >= b.grp_start[xcd][ng]) return;
@@ -1178,55 +1198,55 @@ __global__ __launch_bounds__(512, 1) void wgrad_mfma6_kernel(W4Batch b) {
   const unsigned gword = b.grp[xcd][gi];
   const int jb = gword & 15, split = gword >> 4, cc = pos - b.grp_start[xcd][gi];
   const W4Job& a = b.job[jb];
-  const int ci_pairs = a.Cin / 64;
+  const int ci_pairs = a.Cin / (32 * C::NCH);
   typedef short v4s __attribute__((ext_vector_type(4)));
   typedef short v8s __attribute__((ext_vector_type(8)));
-  __shared__ __attribute__((aligned(16))) unsigned char smem[W6_LDS];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS];
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cb = w8 & 3, ch = w8 >> 2;
-  const int cot4 = cc / ci_pairs, cit2 = cc % ci_pairs;
-  const int co0 = cot4 * 128, ci0 = cit2 * 64;
-  const bool do_bias = (cit2 == 0) && (ch == 0);     // wave-uniform
+  const int cb = w8 % C::NCB, ch = (w8 / C::NCB) % C::NCH, rg = w8 / (C::NCB * C::NCH);
+  const int cotb = cc / ci_pairs, citb = cc % ci_pairs;
+  const int co0 = cotb * 32 * C::NCB, ci0 = citb * 32 * C::NCH;
+  const bool do_bias = (citb == 0) && (ch == 0);     // wave-uniform
 
   // ---- DMA slots of this wave (the kind of slot k is the same for every wave: no branch at the issue site) ----
-  //   k = 0: x instruction w8 (0..7);  k = 1: x instruction 8 + w8 for w8 < 6, else 1 KiB of zeros into the stage's sink;
-  //   k = 2: dy instruction w8;  k = 3: dy instruction 8 + w8.   x instruction xi = 16 halo pixels (x 4 pieces) of
-  //   input-channel half xi / 7; dy instruction di = tile row di & 3 of output-channel block di >> 2.
+  //   k < KX: x instruction xi = w8 + 8 k = 16 halo pixels (x 4 pieces) of input-channel half xi / XI; an xi past the
+  //           last one (shape A: 14, 15) writes 1 KiB of zeros into the stage's sink;
+  //   k >= KX: dy instruction di = w8 + 8 (k - KX) = tile row di % TH of output-channel block di / TH.
   // Per lane: pixel coordinates RELATIVE to the tile origin (halo: -1 ..), the byte offset from the tile's first pixel
   // and a validity flag; range checks against the image are done for every piece (4 VALU instructions) -- a separate
   // interior fast path cost more in branches and kernel-argument reloads (s_load + lgkmcnt(0), which also drains the
   // wave's LDS reads) than it saved.
   int H = a.H, W = a.W;
   asm volatile("" : "+s"(H), "+s"(W));          // keep them in SGPRs (otherwise re-read from the kernel arguments per use)
-  int ldsoff[4];                   // wave-uniform
-  int yy[4], xx[4], rel[4];        // per lane
-  bool pv[4];
+  int ldsoff[C::NSLOT];            // wave-uniform
+  int yy[C::NSLOT], xx[C::NSLOT], rel[C::NSLOT];   // per lane
+  bool pv[C::NSLOT];
   {
     const int pix = lane >> 2, piece = lane & 3;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < C::KX; ++k) {
       const int xi = w8 + 8 * k;
-      const bool sink = xi >= 14;
-      const int h = xi >= 7 ? 1 : 0, i = xi - 7 * h, p = 16 * i + pix;
-      ldsoff[k] = sink ? 4 * W6_DSUB + W6_XB : h * W6_XSUB + i * 1024;
-      pv[k] = !sink && p < W6_NPX;
-      yy[k] = p / W6_HW - 1;
-      xx[k] = p - (p / W6_HW) * W6_HW - 1;
+      const bool sink = xi >= C::NX;
+      const int h = xi / C::XI, i = xi - C::XI * h, p = 16 * i + pix;
+      ldsoff[k] = sink ? C::STG : h * C::XSUB + i * 1024;
+      pv[k] = !sink && p < C::NPX;
+      yy[k] = p / HWp - 1;
+      xx[k] = p - (p / HWp) * HWp - 1;
       rel[k] = (yy[k] * W + xx[k]) * a.Cin * 2 + (ci0 + h * 32 + piece * 8) * 2;
     }
 #pragma unroll
-    for (int k = 2; k < 4; ++k) {
-      const int di = w8 + 8 * (k - 2), c = di >> 2, i = di & 3;
-      ldsoff[k] = W6_XB + c * W6_DSUB + i * 1024;
+    for (int k = C::KX; k < C::NSLOT; ++k) {
+      const int di = w8 + 8 * (k - C::KX), c = di / C::TH_, i = di % C::TH_;
+      ldsoff[k] = C::XB + c * C::DSUB + i * 1024;
       pv[k] = true;
       yy[k] = i;
       xx[k] = pix;
       rel[k] = (i * W + pix) * a.Cout * 2 + (co0 + c * 32 + piece * 8) * 2;
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) ldsoff[k] = __builtin_amdgcn_readfirstlane(ldsoff[k]);
+    for (int k = 0; k < C::NSLOT; ++k) ldsoff[k] = __builtin_amdgcn_readfirstlane(ldsoff[k]);
   }
   const unsigned char* xb = reinterpret_cast<const unsigned char*>(a.x);
   const unsigned char* db = reinterpret_cast<const unsigned char*>(a.dy);
@@ -1239,17 +1259,17 @@ __global__ __launch_bounds__(512, 1) void wgrad_mfma6_kernel(W4Batch b) {
     const int tx_ = t % a.tiles_x; t /= a.tiles_x;
     const int ty_ = t % a.tiles_y;
     const int n = t / a.tiles_y;
-    tp.oy0 = live ? ty_ * W6_TH : 1 << 24; tp.ox0 = tx_ * TW;
-    const size_t pix0 = (size_t)(n * H + ty_ * W6_TH) * W + tp.ox0;
+    tp.oy0 = live ? ty_ * C::TH_ : 1 << 24; tp.ox0 = tx_ * TW;
+    const size_t pix0 = (size_t)(n * H + ty_ * C::TH_) * W + tp.ox0;
     tp.xt = xb + pix0 * a.Cin * 2;
     tp.dt = db + pix0 * a.Cout * 2;
     return tp;
   };
   auto issue_slot = [&](const TilePos& tp, int stage, int k) {     // k is a compile-time constant at every call site
     if (b.diag & 1) return;                                   // tuning aid (wrong results): no tile loads
-    const unsigned sb = __builtin_amdgcn_readfirstlane(lds0 + stage * W6_STGS + ldsoff[k]);   // (wave-uniform: M0)
+    const unsigned sb = __builtin_amdgcn_readfirstlane(lds0 + stage * C::STGS + ldsoff[k]);   // (wave-uniform: M0)
     const bool ok = pv[k] && (unsigned)(tp.oy0 + yy[k]) < (unsigned)H && (unsigned)(tp.ox0 + xx[k]) < (unsigned)W;
-    glds16(ok ? (k < 2 ? tp.xt : tp.dt) + rel[k] : zero, sb);
+    glds16(ok ? (k < C::KX ? tp.xt : tp.dt) + rel[k] : zero, sb);
   };
 
   f32x16 acc[3][3];
@@ -1272,40 +1292,40 @@ __global__ __launch_bounds__(512, 1) void wgrad_mfma6_kernel(W4Batch b) {
   const int ntl = a.ntiles > split ? (a.ntiles - split + a.S - 1) / a.S : 0;
   auto tile_of = [&](int k) { return k < ntl ? split + k * a.S : a.ntiles; };   // (past the end: zeros)
 #pragma unroll
-  for (int s = 0; s < W6_DP; ++s) {
+  for (int s = 0; s < C::DP; ++s) {
     const TilePos tp = locate(tile_of(s));
 #pragma unroll
-    for (int k = 0; k < 4; ++k) issue_slot(tp, s, k);
+    for (int k = 0; k < C::NSLOT; ++k) issue_slot(tp, s, k);
   }
-  // first fragments of a tile: its four dy fragments (output rows 0..3 of this wave's output-channel block) and the x
-  // fragments 0, 1 (halo row 0, kw 0 and 1) of this wave's input-channel half
+  // first fragments of a tile: the four dy fragments of this wave's output rows (row group rg) and output-channel block,
+  // and the x fragments 0, 1 (first halo row of the row group, kw 0 and 1) of this wave's input-channel half
   bf16x8 dfr[4], xcur, xq1;
-  auto xfrag_at = [&](const unsigned char* lX, int f) { return tr_frag(lX + fbase + ((f / 3) * W6_HW + f % 3) * PP); };
+  auto xfrag_at = [&](const unsigned char* lX, int f) { return tr_frag(lX + fbase + ((4 * rg + f / 3) * HWp + f % 3) * PP); };
   auto first_frags = [&](int slot) {
-    const unsigned char* lS = smem + slot * W6_STGS;
+    const unsigned char* lS = smem + slot * C::STGS;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) dfr[r] = tr_frag(lS + W6_XB + cb * W6_DSUB + fbase + r * TW * PP);
-    xcur = xfrag_at(lS + ch * W6_XSUB, 0);
-    xq1 = xfrag_at(lS + ch * W6_XSUB, 1);
+    for (int r = 0; r < 4; ++r) dfr[r] = tr_frag(lS + C::XB + cb * C::DSUB + fbase + (4 * rg + r) * TW * PP);
+    xcur = xfrag_at(lS + ch * C::XSUB, 0);
+    xq1 = xfrag_at(lS + ch * C::XSUB, 1);
   };
-  wait_vmcnt<4 * (W6_DP - 1)>();        // tile 0 has landed (this wave's pieces) ...
-  __builtin_amdgcn_s_barrier();         // ... and everyone's
+  wait_vmcnt<C::NSLOT * (C::DP - 1)>();   // tile 0 has landed (this wave's pieces) ...
+  __builtin_amdgcn_s_barrier();           // ... and everyone's
   first_frags(0);
 
   int ps = 0;
   for (int it = 0; it < ntl; ++it) {
-    int fs = ps + W6_DP;
-    fs = fs >= W6_NST ? fs - W6_NST : fs;
-    const int ns = ps + 1 == W6_NST ? 0 : ps + 1;
-    const TilePos ft = locate(tile_of(it + W6_DP));
-    // tile it+1 has landed for every wave (tile it+2 may fly); every wave is also done reading tile it-1's slot, which
-    // this iteration refills with tile it+DP
-    wait_vmcnt<4 * (W6_DP - 2)>();
+    int fs = ps + C::DP;
+    fs = fs >= C::NST ? fs - C::NST : fs;
+    const int ns = ps + 1 == C::NST ? 0 : ps + 1;
+    const TilePos ft = locate(tile_of(it + C::DP));
+    // tile it+1 has landed for every wave (younger tiles may fly); every wave is also done reading tile it-1's slot,
+    // which this iteration refills with tile it+DP
+    wait_vmcnt<C::NSLOT * (C::DP - 2)>();
     __builtin_amdgcn_s_barrier();
-    const unsigned char* lX = smem + ps * W6_STGS + ch * W6_XSUB;
+    const unsigned char* lX = smem + ps * C::STGS + ch * C::XSUB;
     if (b.diag & 2) {                     // tuning aid (wrong results): loads only
 #pragma unroll
-      for (int k = 0; k < 4; ++k) issue_slot(ft, fs, k);
+      for (int k = 0; k < C::NSLOT; ++k) issue_slot(ft, fs, k);
       ps = ns;
       continue;
     }
@@ -1319,7 +1339,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_mfma6_kernel(W4Batch b) {
         bsum += s8;
       }
     }
-    // 18 x fragments: halo rows 0..5 (rr) x kw; fragment f+2 is read while fragment f's MFMAs issue
+    // 18 x fragments: halo rows 0..5 of the row group (rr) x kw; fragment f+2 is read while fragment f's MFMAs issue
 #pragma unroll
     for (int f = 0; f < 18; ++f) {
       const int rr = f / 3, kw = f % 3;
@@ -1330,10 +1350,19 @@ __global__ __launch_bounds__(512, 1) void wgrad_mfma6_kernel(W4Batch b) {
         const int r = rr - kh;          // halo row rr = output row r + kh
         if (r >= 0 && r < 4) acc[kh][kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfr[r], xcur, acc[kh][kw], 0, 0, 0);
       }
-      if (f == 2) issue_slot(ft, fs, 0);
-      if (f == 6) issue_slot(ft, fs, 1);
-      if (f == 10) issue_slot(ft, fs, 2);
-      if (f == 14) issue_slot(ft, fs, 3);
+      // this wave's DMA pieces of tile it+DP, spread over the fragment steps
+      if (C::NSLOT == 4) {
+        if (f == 2) issue_slot(ft, fs, 0);
+        if (f == 6) issue_slot(ft, fs, 1);
+        if (f == 10) issue_slot(ft, fs, 2);
+        if (f == 14) issue_slot(ft, fs, 3);
+      } else {
+        if (f == 2) issue_slot(ft, fs, 0);
+        if (f == 5) issue_slot(ft, fs, 1);
+        if (f == 8) issue_slot(ft, fs, 2);
+        if (f == 11) issue_slot(ft, fs, 3);
+        if (f == 14) issue_slot(ft, fs, C::NSLOT - 1);
+      }
       if (f + 2 < 18) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
       {
         const int nm = (rr == 0 || rr == 5) ? 1 : ((rr == 1 || rr == 4) ? 2 : 3);
@@ -1350,9 +1379,44 @@ __global__ __launch_bounds__(512, 1) void wgrad_mfma6_kernel(W4Batch b) {
   }
   wait_vmcnt<0>();                       // the zero-page pieces of the tiles past the end
 
-  // ---- every wave owns its 32co x 32ci x 9 block outright: store it in the slab's block order ----
   const int ci = lane & 31, hsel = lane >> 5;
-  const int cc32 = (4 * cot4 + cb) * (a.Cin / 32) + 2 * cit2 + ch;
+  if (do_bias) bsum += __shfl_xor(bsum, 32, 64);      // lanes l and l + 32 hold the two pixel halves of output channel l
+  if constexpr (C::NRG == 2) {
+    // ---- the two row groups hold partial sums of the same blocks: group 1 -> LDS images, group 0 adds (fixed order) ----
+    __syncthreads();                      // every wave is done with the ring: it becomes the reduction scratch
+    float* red = reinterpret_cast<float*>(smem) + (cb + C::NCB * ch) * 5120;
+    float* bred = reinterpret_cast<float*>(smem) + C::NCB * C::NCH * 5120;
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+      if (round) __syncthreads();         // group 0 is done reading round 0's images
+      if (rg == 1) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+          if ((t < 5) == (round == 0))
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4)
+              *(f32x4*)(red + (t - 5 * round) * 1024 + ci * 32 + (((2 * q4 + hsel) ^ (ci & 7)) << 2)) =
+                  f32x4{acc[t / 3][t % 3][4 * q4], acc[t / 3][t % 3][4 * q4 + 1], acc[t / 3][t % 3][4 * q4 + 2], acc[t / 3][t % 3][4 * q4 + 3]};
+        if (round == 0 && do_bias && lane < 32) bred[cb * 32 + lane] = bsum;
+      }
+      __syncthreads();
+      if (rg == 0) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+          if ((t < 5) == (round == 0))
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+              const f32x4 v = *(const f32x4*)(red + (t - 5 * round) * 1024 + ci * 32 + (((2 * q4 + hsel) ^ (ci & 7)) << 2));
+#pragma unroll
+              for (int j = 0; j < 4; ++j) acc[t / 3][t % 3][4 * q4 + j] += v[j];
+            }
+        if (round == 0 && do_bias && lane < 32) bsum += bred[cb * 32 + lane];
+      }
+    }
+    if (rg == 1) return;
+  }
+  // ---- a wave owns its 32co x 32ci x 9 block outright: store it in the slab's block order ----
+  const int cc32 = (C::NCB * cotb + cb) * (a.Cin / 32) + C::NCH * citb + ch;
   float* blk = a.slab + (size_t)split * a.slab_stride + (size_t)cc32 * 9216;
 #pragma unroll
   for (int kh = 0; kh < 3; ++kh)
@@ -1362,10 +1426,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_mfma6_kernel(W4Batch b) {
       for (int q4 = 0; q4 < 4; ++q4)
         *(f32x4*)(blk + (kh * 3 + kw) * 1024 + ci * 32 + (((2 * q4 + hsel) ^ (ci & 7)) << 2)) =
             f32x4{acc[kh][kw][4 * q4], acc[kh][kw][4 * q4 + 1], acc[kh][kw][4 * q4 + 2], acc[kh][kw][4 * q4 + 3]};
-  if (do_bias) {       // lanes l and l + 32 hold the two pixel halves of output channel l
-    const float t = bsum + __shfl_xor(bsum, 32, 64);
-    if (lane < 32) a.slab[(size_t)split * a.slab_stride + (size_t)9 * a.Cout * a.Cin + co0 + cb * 32 + lane] = t;
-  }
+  if (do_bias && lane < 32) a.slab[(size_t)split * a.slab_stride + (size_t)9 * a.Cout * a.Cin + co0 + cb * 32 + lane] = bsum;
 }
 
 // Slab reduction of the v4 layout: slab s = [(co,ci) block cc][tap][ci][co quad ^ (ci & 7)][4 co] + Cout bias sums.
@@ -1477,20 +1538,29 @@ void launch_wt(const WgArgs& a, int co_t, int ci_t, int grid_y, hipStream_t st) 
 
 // ---- v4 batch planning (host) -------------------------------------------------------------------------------------
 // Kernel mode of a job (W4Job::cob2): 0 = pairs of tiles, 32co x 32ci per workgroup; 1 = two output-channel blocks per
-// workgroup (Cout % 64 == 0); 2 = the v6 kernel, 128co x 64ci per workgroup on 4 x 16-pixel tiles (Cout % 128 == 0 and
-// Cin % 64 == 0; PTI_WGRAD_V6=1, read per call: the A/B tool toggles it inside one process).
-static bool w6_wanted(int cin, int cout) {
+// workgroup (Cout % 64 == 0); the v6 kernel: 2 = shape A, 128co x 64ci per workgroup on 4 x 16-pixel tiles (Cout % 128 ==
+// 0 and Cin % 64 == 0), 3 = shape B, 64co x 64ci on 8 x 16-pixel tiles (Cout % 64 == 0 and Cin % 64 == 0).
+// PTI_WGRAD_V6 (read per call: the A/B tool toggles it inside one process): 0 = never, 1 = shape A only (the default),
+// 2 = A and B.  Shape B is 20-28 % faster than v4's two-block mode launch for launch (64->64@128^2 80 -> 57 us,
+// @256^2 216 -> 166 us = 933 TFLOP/s) and still costs the training step of config A +0.15 ms when it replaces it (same
+// box, interleaved, three runs; with a 160-KiB or a 120-KiB ring, 512 to 2048 workgroups): its jobs -- the 64-channel
+// layers' weight gradients -- run beside the HBM-bound 32-channel data-gradient chain on the other stream, and the
+// faster kernel takes bandwidth from that critical path.  Kept selectable; not the default.
+static int w6_mode(int cin, int cout) {
   const char* e = getenv("PTI_WGRAD_V6");
-  return e && atoi(e) != 0 && cout % 128 == 0 && cin % 64 == 0;
+  const int v = e ? atoi(e) : 1;
+  if (v >= 1 && cout % 128 == 0 && cin % 64 == 0) return 2;
+  if (v >= 2 && cout % 64 == 0 && cin % 64 == 0) return 3;
+  return 0;
 }
-static void w4_fill_job(W4Job& a, const void* x, const void* dy, int n, int h, int w, int cin, int cout, bool v6 = false) {
+static void w4_fill_job(W4Job& a, const void* x, const void* dy, int n, int h, int w, int cin, int cout, int v6 = 0) {
   a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.slab = nullptr;
   a.N = n; a.H = h; a.W = w; a.Cin = cin; a.Cout = cout;
-  a.tiles_x = cdiv(w, TW); a.tiles_y = cdiv(h, v6 ? W6_TH : TH); a.ntiles = n * a.tiles_x * a.tiles_y;
+  a.tiles_x = cdiv(w, TW); a.tiles_y = cdiv(h, v6 == 2 ? W6A::TH_ : TH); a.ntiles = n * a.tiles_x * a.tiles_y;
   a.slab_stride = (long long)9 * cout * cin + cout;
   a.S = 1;
   static const int cob2_env = getenv("PTI_WGRAD_V4_COB2") ? atoi(getenv("PTI_WGRAD_V4_COB2")) : 1;
-  a.cob2 = v6 ? 2 : ((cob2_env && cout % 64 == 0) ? 1 : 0);
+  a.cob2 = v6 ? v6 : ((cob2_env && cout % 64 == 0) ? 1 : 0);
 }
 static bool w4_eligible(int n, int h, int w, int cin, int cout) {
   return n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && cin % 32 == 0 && cout % 32 == 0 &&
@@ -1521,11 +1591,12 @@ static long long w4_plan(W4Batch& b, float* workspace, long long workspace_float
   b.diag = diag_env;
   // workgroups of one pixel split: (co, ci) blocks of 32 x 32, or of 64 x 32 in the two-block mode
   auto tiles32 = [](const W4Job& a) {
-    return a.cob2 == 2 ? (a.Cin / 64) * (a.Cout / 128) : (a.Cin / 32) * (a.Cout / (a.cob2 ? 64 : 32));
+    return a.cob2 == 2 ? (a.Cin / 64) * (a.Cout / 128) : a.cob2 == 3 ? (a.Cin / 64) * (a.Cout / 64)
+                                                                     : (a.Cin / 32) * (a.Cout / (a.cob2 ? 64 : 32));
   };
   // v6 batches (every job in mode 2): a workgroup writes EIGHT 37-KB blocks, so the launch aims at fewer, longer
   // workgroups (PTI_WGRAD_V6_WGS, default 512 = two rounds per CU); work is counted in workgroup-tiles
-  const bool m6 = b.njobs > 0 && b.job[0].cob2 == 2;
+  const bool m6 = b.njobs > 0 && b.job[0].cob2 >= 2;
   const char* w6e = getenv("PTI_WGRAD_V6_WGS");
   const int wgs6 = w6e && atoi(w6e) > 0 ? atoi(w6e) : 512;
   double work = 0;   // 32 x 32-block tiles of the whole launch (a two-block workgroup does two per pixel tile)
@@ -1661,14 +1732,15 @@ extern "C" int pti_conv_wgrad_mfma_partials(const void* x, const void* dy, const
   if (v4) {
     W4Batch b;
     b.njobs = 1;
-    w4_fill_job(b.job[0], x, dy, d->n, d->h, d->w, d->cin, d->cout, w6_wanted(d->cin, d->cout));
+    w4_fill_job(b.job[0], x, dy, d->n, d->h, d->w, d->cin, d->cout, w6_mode(d->cin, d->cout));
     b.dw[0] = b.dbias[0] = nullptr;
     b.accumulate[0] = 0;
     if (w4_plan(b, (float*)workspace, workspace_bytes / 4) < 0)
       PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma: workspace too small (%lld bytes per split needed)", a.slab_stride * 4);
     const char* v5e = getenv("PTI_WGRAD_V5");     // (read per call here: the A/B tool toggles it inside one process)
     const bool v5 = v5e && atoi(v5e) != 0 && !b.diag;
-    if (b.job[0].cob2 == 2) PTI_LAUNCH(wgrad_mfma6_kernel, dim3(b.nwg), dim3(512), 0, (hipStream_t)s, b);
+    if (b.job[0].cob2 == 2) PTI_LAUNCH(wgrad_mfma6_kernel<W6A>, dim3(b.nwg), dim3(512), 0, (hipStream_t)s, b);
+    else if (b.job[0].cob2 == 3) PTI_LAUNCH(wgrad_mfma6_kernel<W6B>, dim3(b.nwg), dim3(512), 0, (hipStream_t)s, b);
     else if (b.job[0].cob2 && v5) PTI_LAUNCH(wgrad_mfma5_kernel, dim3(b.nwg), dim3(256), 0, (hipStream_t)s, b);
     else if (b.job[0].cob2) PTI_LAUNCH(wgrad_mfma4_kernel<true>, dim3(b.nwg), dim3(512), 0, (hipStream_t)s, b);
     else PTI_LAUNCH(wgrad_mfma4_kernel<false>, dim3(b.nwg), dim3(512), 0, (hipStream_t)s, b);
@@ -1730,8 +1802,8 @@ extern "C" int pti_conv_wgrad_mfma_batched(const pti_wgrad_job* jobs, int njobs,
   if (!jobs || !workspace || njobs < 1 || njobs > PTI_WGRAD_BATCH_MAX)
     PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma_batched: 1..%d jobs", PTI_WGRAD_BATCH_MAX);
   // one batch per kernel mode (see w4_fill_job); each gets its own launch pair and its own part of the workspace
-  W4Batch bm[3];
-  bm[0].njobs = bm[1].njobs = bm[2].njobs = 0;
+  W4Batch bm[4];
+  bm[0].njobs = bm[1].njobs = bm[2].njobs = bm[3].njobs = 0;
   for (int j = 0; j < njobs; ++j) {
     const pti_wgrad_job& q = jobs[j];
     if (!q.x || !q.dy || !q.dw) PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma_batched: job %d has a null pointer", j);
@@ -1739,7 +1811,7 @@ extern "C" int pti_conv_wgrad_mfma_batched(const pti_wgrad_job* jobs, int njobs,
       PTI_FAIL(PTI_EUNSUPPORTED, "conv_wgrad_mfma_batched: job %d: n=%d h=%d w=%d cin=%d cout=%d (channels must be multiples of 32, tensors < 2 GiB)",
                j, q.n, q.h, q.w, q.cin, q.cout);
     W4Job jb;
-    w4_fill_job(jb, q.x, q.dy, q.n, q.h, q.w, q.cin, q.cout, w6_wanted(q.cin, q.cout));
+    w4_fill_job(jb, q.x, q.dy, q.n, q.h, q.w, q.cin, q.cout, w6_mode(q.cin, q.cout));
     W4Batch& b = bm[jb.cob2];
     const int k = b.njobs++;
     b.job[k] = jb;
@@ -1750,7 +1822,7 @@ extern "C" int pti_conv_wgrad_mfma_batched(const pti_wgrad_job* jobs, int njobs,
   const char* v5e = getenv("PTI_WGRAD_V5");
   const int v5_env = v5e ? atoi(v5e) : 0;
   const void* main_kernel = nullptr;
-  for (int m = 2; m >= 0; --m) {      // the widest blocks first (they are the larger batches on every model of the reference)
+  for (int m = 3; m >= 0; --m) {      // the v6 batches and the widest blocks first (they are the larger batches on every model of the reference)
     W4Batch& b = bm[m];
     if (b.njobs == 0) continue;
     // a batch that is followed by another one may take at most 3/4 of what is left of the workspace
@@ -1764,7 +1836,8 @@ extern "C" int pti_conv_wgrad_mfma_batched(const pti_wgrad_job* jobs, int njobs,
     // two-block jobs: PTI_WGRAD_V5=1 selects the one-wave-per-SIMD kernel (v5; bit-identical results, measured 15-48 %
     // SLOWER than v4 in round 3 -- see the note above wgrad_mfma5_kernel -- hence off by default)
     const void* kfn;
-    if (m == 2) { PTI_LAUNCH(wgrad_mfma6_kernel, dim3(b.nwg), dim3(512), 0, (hipStream_t)s, b); kfn = reinterpret_cast<const void*>(wgrad_mfma6_kernel); }
+    if (m == 3) { PTI_LAUNCH(wgrad_mfma6_kernel<W6B>, dim3(b.nwg), dim3(512), 0, (hipStream_t)s, b); kfn = reinterpret_cast<const void*>(wgrad_mfma6_kernel<W6B>); }
+    else if (m == 2) { PTI_LAUNCH(wgrad_mfma6_kernel<W6A>, dim3(b.nwg), dim3(512), 0, (hipStream_t)s, b); kfn = reinterpret_cast<const void*>(wgrad_mfma6_kernel<W6A>); }
     else if (m == 1 && v5_env && !b.diag) { PTI_LAUNCH(wgrad_mfma5_kernel, dim3(b.nwg), dim3(256), 0, (hipStream_t)s, b); kfn = reinterpret_cast<const void*>(wgrad_mfma5_kernel); }
     else if (m == 1) { PTI_LAUNCH(wgrad_mfma4_kernel<true>, dim3(b.nwg), dim3(512), 0, (hipStream_t)s, b); kfn = reinterpret_cast<const void*>(wgrad_mfma4_kernel<true>); }
     else { PTI_LAUNCH(wgrad_mfma4_kernel<false>, dim3(b.nwg), dim3(512), 0, (hipStream_t)s, b); kfn = reinterpret_cast<const void*>(wgrad_mfma4_kernel<false>); }

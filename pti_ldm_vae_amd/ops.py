@@ -342,14 +342,23 @@ def conv_wgrad_mfma_batched(jobs, workspace=None, accumulate=True):
         L.check(L.lib().pti_conv_wgrad_mfma_batched(arr, len(jobs), _ptr(ws), ws.numel() * 4, _stream()),
                 "pti_conv_wgrad_mfma_batched")
         return
-    # profiling: the library launches one kernel per mode (two output-channel blocks per workgroup for Cout % 64 == 0,
-    # tile pairs otherwise); issue the two groups as two calls so that each kernel gets its own record (its own
-    # algorithmic work, its own duration = partial launch + the <1 % reduction launch) under its own name
+    # profiling: the library launches one kernel per mode (wgrad_mfma.hip, w4_fill_job: the v6 kernel's two shapes, two
+    # output-channel blocks per workgroup for Cout % 64 == 0, tile pairs otherwise); issue the groups as separate calls
+    # so that each kernel gets its own record (its own algorithmic work, its own duration = partial launch + the <1 %
+    # reduction launch) under its own name
     cob2 = os.environ.get("PTI_WGRAD_V4_COB2", "1") != "0"
+    v6 = int(os.environ.get("PTI_WGRAD_V6", "1") or 0)
+
+    def mode_of(cin, cout):
+        if v6 >= 1 and cout % 128 == 0 and cin % 64 == 0:
+            return 2
+        if v6 >= 2 and cout % 64 == 0 and cin % 64 == 0:
+            return 3
+        return 1 if cob2 and cout % 64 == 0 else 0
     groups = {}
     for i, (x, dy, dw, db) in enumerate(jobs):
-        groups.setdefault(bool(cob2 and dy.shape[3] % 64 == 0), []).append(i)
-    for mode in (True, False):
+        groups.setdefault(mode_of(x.shape[3], dy.shape[3]), []).append(i)
+    for mode in (3, 2, 1, 0):
         idx = groups.get(mode)
         if not idx:
             continue

@@ -11,6 +11,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pti_ldm_vae_amd import ops  # noqa: E402
 
+os.environ["PTI_WGRAD_V6"] = "0"      # compare v5 with v4 (v6 would otherwise take the >= 128-channel shapes)
 dev = torch.device("cuda:0")
 B = int(os.environ.get("BATCH", "32"))
 SHAPES = [(64, 64, 128), (128, 64, 128), (128, 128, 64), (64, 128, 64), (128, 128, 32), (128, 128, 128), (256, 256, 64), (128, 256, 64)]

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Interleaved A/B (one process) of the 128co x 64ci weight-gradient kernel (wgrad_mfma6_kernel, PTI_WGRAD_V6=1) against
+"""Interleaved A/B (one process) of the 128co x 64ci weight-gradient kernel (wgrad_mfma6_kernel, both shapes: PTI_WGRAD_V6=2) against
 the v4 kernel's two-block mode on the >= 128-channel 3x3 layers of config A (batch 32) and the AR model, with the results
 compared (same slab layout and reduction; fp32 summation order over pixels differs) and, on small ragged shapes, checked
 against torch's fp32 weight gradient.  PTI_WGRAD_V6 is read per call.  usage: python tools/bench_wgrad_v6.py"""
@@ -13,7 +13,7 @@ from pti_ldm_vae_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
 B = int(os.environ.get("BATCH", "32"))
-SHAPES = [(128, 128, 32), (128, 128, 64), (64, 128, 128), (128, 128, 128), (256, 256, 64), (128, 256, 64), (256, 256, 32)]
+SHAPES = [(64, 64, 128), (128, 64, 128), (64, 64, 256), (128, 128, 32), (128, 128, 64), (64, 128, 128), (128, 128, 128), (256, 256, 64), (128, 256, 64), (256, 256, 32)]
 
 
 def timeit(fn, iters=20):
@@ -30,7 +30,7 @@ def timeit(fn, iters=20):
 
 
 def run(x, dy, v6):
-    os.environ["PTI_WGRAD_V6"] = "1" if v6 else "0"
+    os.environ["PTI_WGRAD_V6"] = "2" if v6 else "0"
     cout, cin = dy.shape[3], x.shape[3]
     dw, db = torch.zeros(cout, cin, 3, 3, device=dev), torch.zeros(cout, device=dev)
     ops.conv_wgrad_mfma(x, dy, dw, db)
@@ -40,7 +40,8 @@ def run(x, dy, v6):
 
 # ---- correctness on ragged shapes against torch (fp32 conv of the same bf16 values) ----
 CHECK = os.environ.get("SKIP_CHECK", "0") != "1"      # (skipped under the wrong-result tuning aids)
-for n, h, w, cin, cout in [] if not CHECK else [(2, 8, 16, 64, 128), (3, 13, 21, 64, 128), (2, 30, 20, 128, 128), (1, 4, 16, 128, 256), (5, 7, 5, 64, 128)]:
+for n, h, w, cin, cout in [] if not CHECK else [(2, 8, 16, 64, 128), (3, 13, 21, 64, 128), (2, 30, 20, 128, 128), (1, 4, 16, 128, 256), (5, 7, 5, 64, 128),
+                             (2, 8, 16, 64, 64), (3, 13, 21, 128, 64), (2, 30, 20, 64, 64), (1, 3, 40, 64, 192), (4, 17, 9, 192, 64)]:
     g = torch.Generator(device=dev).manual_seed(h * 100 + w)
     x = torch.randn(n, h, w, cin, device=dev, generator=g).bfloat16()
     dy = torch.randn(n, h, w, cout, device=dev, generator=g).bfloat16()
@@ -68,7 +69,7 @@ for cin, cout, hw in SHAPES:
         res[k] = run(x, dy, k)
     for _ in range(2):
         for k in (False, True):
-            os.environ["PTI_WGRAD_V6"] = "1" if k else "0"
+            os.environ["PTI_WGRAD_V6"] = "2" if k else "0"
             dw, db = torch.zeros(cout, cin, 3, 3, device=dev), torch.zeros(cout, device=dev)
             t.setdefault(k, []).append(timeit(lambda: ops.conv_wgrad_mfma(x, dy, dw, db)))
     rel = ((res[True][0] - res[False][0]).norm() / res[False][0].norm()).item()
