@@ -1180,15 +1180,22 @@ struct W6Cfg {
   // kept at <= 124 KiB: a workgroup that takes the whole LDS (v4: 160 KiB) keeps every other kernel off its CU, and the
   // training step runs the data-gradient chain on the other stream (B with a four-stage 160-KiB ring: +0.2 ms per step)
   static constexpr int FOLD = NRG == 2 ? NCB * NCH * 5 * 1024 * 4 + 1024 : 0;
+#ifdef W6_NST3
+  static constexpr int NST = 3, DP = 2;
+#else
   static constexpr int NST = (124 * 1024) / STGS >= 4 ? 4 : 3, DP = NST - 1;
+#endif
   static constexpr int LDS = NST * STGS > FOLD ? NST * STGS : FOLD;
   static_assert(NCB * NCH * NRG == 8 && ND % 8 == 0 && LDS <= 160 * 1024 && NSLOT * (DP - 1) <= 63, "v6 shape");
 };
 using W6A = W6Cfg<4, 2, 1>;
 using W6B = W6Cfg<2, 2, 2>;
 
+#ifndef W6_VGPR_ATTR
+#define W6_VGPR_ATTR
+#endif
 template <class C>
-__global__ __launch_bounds__(512, 1) void wgrad_mfma6_kernel(W4Batch b) {
+__global__ W6_VGPR_ATTR __launch_bounds__(512, 1) void wgrad_mfma6_kernel(W4Batch b) {
   constexpr int PP = 64, HWp = C::HW_;
   const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
   const int ng = b.ngrp[xcd];
@@ -1822,13 +1829,23 @@ extern "C" int pti_conv_wgrad_mfma_batched(const pti_wgrad_job* jobs, int njobs,
   const char* v5e = getenv("PTI_WGRAD_V5");
   const int v5_env = v5e ? atoi(v5e) : 0;
   const void* main_kernel = nullptr;
-  for (int m = 3; m >= 0; --m) {      // the v6 batches and the widest blocks first (they are the larger batches on every model of the reference)
+  // every batch gets the share of the workspace that its one-split-per-job minimum has in the call's (the same average
+  // number of splits per job everywhere; what a batch does not use goes to the next one)
+  long long need[4] = {0, 0, 0, 0}, need_all = 0;
+  for (int m = 0; m < 4; ++m) {
+    for (int j = 0; j < bm[m].njobs; ++j) need[m] += bm[m].job[j].slab_stride;
+    need_all += need[m];
+  }
+  if (need_all > ws_floats) PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma_batched: workspace too small (%lld bytes needed for one split per job)", need_all * 4);
+  const long long ws_total = ws_floats;
+  for (int m = 3; m >= 0; --m) {      // the v6 batches and the widest blocks first
     W4Batch& b = bm[m];
     if (b.njobs == 0) continue;
-    // a batch that is followed by another one may take at most 3/4 of what is left of the workspace
-    bool more = false;
-    for (int m2 = m - 1; m2 >= 0; --m2) more = more || bm[m2].njobs > 0;
-    const long long avail = more ? ws_floats * 3 / 4 : ws_floats;
+    long long later = 0;
+    for (int m2 = m - 1; m2 >= 0; --m2) later += need[m2];
+    long long avail = (long long)((double)ws_total * ((double)need[m] / (double)need_all));
+    if (avail < need[m]) avail = need[m];
+    if (later == 0 || avail > ws_floats - later) avail = ws_floats - later;
     const long long used = w4_plan(b, ws, avail);
     if (used < 0) PTI_FAIL(PTI_EINVAL, "conv_wgrad_mfma_batched: workspace too small");
     ws += used;

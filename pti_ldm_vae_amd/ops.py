@@ -250,8 +250,10 @@ def wgrad_direct(wide, narrow, dw, *, n, h, w, cw, cn, ksize, sgn, narrow_layout
 _WS = {}
 
 
-def wgrad_workspace(device, nbytes=48 << 20):
-    """One reusable split-K workspace per device (slabs of fp32 partial weight gradients)."""
+def wgrad_workspace(device, nbytes=int(os.environ.get("PTI_WGRAD_WORKSPACE_MB", "256")) << 20):
+    """One reusable split-K workspace per device (slabs of fp32 partial weight gradients).  256 MB by default: a 256 -> 256
+    layer's slab is 2.4 MB per pixel split, and a batched launch of 16 such layers that can afford only one or two splits
+    per layer has fewer workgroups than the chip has CUs (round 2's 48 MB did that to the AR model's batches)."""
     key = (device.index if device.index is not None else torch.cuda.current_device())
     ws = _WS.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
