@@ -394,6 +394,13 @@ int pti_squeeze_conv1_fwd(const float* x, const float* w10, void* y, int n, int 
 int pti_squeeze_conv1_bwd(const void* g, const void* t0, const float* w10, float* dx, int n, int h, int w, pti_stream_t s);
 int pti_nchw_f32_to_nhwc_f16(const float* x, void* y, int n, int c, int hw, pti_stream_t s);
 int pti_nhwc_bf16_add_to_nchw_f32(const void* g, float* y, int n, int c, int hw, pti_stream_t s);
+/* Image-side boundary of the MFMA path for 2..8-channel images (csrc/narrow_pad.hip; replaces nothing in the reference:
+ * conv_in / conv_out of MONAI's AutoencoderKL, src/pti_ldm_vae/models/autoencoder.py:67-79, take [N,C,H,W] fp32 images):
+ *   pti_pad_nchw_to_nhwc32:   ya, yb [n][hw][32] 16-bit (fp16 if *_f16 else bf16; yb may be NULL) <- x [n][c][hw] fp32,
+ *                             channels >= c written as zeros; 1 <= c <= 8.
+ *   pti_slice_nhwc32_to_nchw: y [n][c][hw] fp32 <- the first c channels of x [n][hw][32] (fp16 if x_f16 else bf16). */
+int pti_pad_nchw_to_nhwc32(const float* x, void* ya, void* yb, int n, int c, int hw, int a_f16, int b_f16, pti_stream_t s);
+int pti_slice_nhwc32_to_nchw(const void* x, float* y, int n, int c, int hw, int x_f16, pti_stream_t s);
 int pti_lpips_tap_nhwc_blocks(int c, int hw);
 int pti_lpips_tap_nhwc_fwd(const void* a, const void* b, const float* w, float* saved, float* partials, int n, int c,
                            int hw, pti_stream_t s);

@@ -122,6 +122,8 @@ SIGNATURES = {
     "pti_squeeze_conv1_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "pti_squeeze_conv1_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "pti_nchw_f32_to_nhwc_f16": (_I, [_P, _P, _I, _I, _I, _P]),
+    "pti_pad_nchw_to_nhwc32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "pti_slice_nhwc32_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "pti_nhwc_bf16_add_to_nchw_f32": (_I, [_P, _P, _I, _I, _I, _P]),
     "pti_lpips_tap_nhwc_blocks": (_I, [_I, _I]),
     "pti_lpips_tap_nhwc_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),

@@ -845,9 +845,12 @@ int launch2_cfg(ConvArgs a, hipStream_t st) {
   // = 168 VGPRs for those launches, compile-time prologue + packed SiLU, no spills: 32->32 152 -> 146 us alone, but
   // the training step got 1.5 % slower -- fewer resident waves overlap worse with the weight-gradient stream)
   constexpr int FPRO = PXF == 4 ? PTI_PRO_GN_SILU : -1;
+  // (GroupNorm WITHOUT SiLU + side output -- the decoder's conv_out on the zero-padded image tile, csrc/narrow_pad.hip --
+  //  takes the same instantiation where its prologue is a run-time flag, i.e. on the 32/64-wide tiles)
+  const bool fwd_gn_rt = fm == 1 && a.prologue == PTI_PRO_GN && !a.gn_mode && !a.pool2 && FPRO < 0;
   if constexpr (KS == 3) {   // the activated-input side output is a separate instantiation (3x3 only)
     if (a.act_out) {
-      if (fwd_silu) PTI_LAUNCH((conv_mfma2_kernel<KS, CK, CT, PXF, true, 1, FPRO>), grid, dim3(256), 0, st, a);
+      if (fwd_silu || fwd_gn_rt) PTI_LAUNCH((conv_mfma2_kernel<KS, CK, CT, PXF, true, 1, FPRO>), grid, dim3(256), 0, st, a);
       else if (a.w_f16) return 2;
       else PTI_LAUNCH((conv_mfma2_kernel<KS, CK, CT, PXF, true, 0, -1>), grid, dim3(256), 0, st, a);
       return 0;

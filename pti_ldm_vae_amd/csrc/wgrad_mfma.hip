@@ -1308,16 +1308,13 @@ __global__ W6_VGPR_ATTR __launch_bounds__(512, 1) void wgrad_mfma6_kernel(W4Batc
   // and the x fragments 0, 1 (first halo row of the row group, kw 0 and 1) of this wave's input-channel half
   bf16x8 dfr[4], xcur, xq1;
   auto xfrag_at = [&](const unsigned char* lX, int f) { return tr_frag(lX + fbase + ((4 * rg + f / 3) * HWp + f % 3) * PP); };
-  auto first_frags = [&](int slot) {
-    const unsigned char* lS = smem + slot * C::STGS;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) dfr[r] = tr_frag(lS + C::XB + cb * C::DSUB + fbase + (4 * rg + r) * TW * PP);
-    xcur = xfrag_at(lS + ch * C::XSUB, 0);
-    xq1 = xfrag_at(lS + ch * C::XSUB, 1);
-  };
+  auto dfrag_at = [&](const unsigned char* lS, int r) { return tr_frag(lS + C::XB + cb * C::DSUB + fbase + (4 * rg + r) * TW * PP); };
   wait_vmcnt<C::NSLOT * (C::DP - 1)>();   // tile 0 has landed (this wave's pieces) ...
   __builtin_amdgcn_s_barrier();           // ... and everyone's
-  first_frags(0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) dfr[r] = dfrag_at(smem, r);
+  xcur = xfrag_at(smem + ch * C::XSUB, 0);
+  xq1 = xfrag_at(smem + ch * C::XSUB, 1);
 
   int ps = 0;
   for (int it = 0; it < ntl; ++it) {
@@ -1330,6 +1327,7 @@ __global__ W6_VGPR_ATTR __launch_bounds__(512, 1) void wgrad_mfma6_kernel(W4Batc
     wait_vmcnt<C::NSLOT * (C::DP - 2)>();
     __builtin_amdgcn_s_barrier();
     const unsigned char* lX = smem + ps * C::STGS + ch * C::XSUB;
+    const unsigned char* lN = smem + ns * C::STGS;            // tile it+1: confirmed by the barrier above
     if (b.diag & 2) {                     // tuning aid (wrong results): loads only
 #pragma unroll
       for (int k = 0; k < C::NSLOT; ++k) issue_slot(ft, fs, k);
@@ -1346,12 +1344,18 @@ __global__ W6_VGPR_ATTR __launch_bounds__(512, 1) void wgrad_mfma6_kernel(W4Batc
         bsum += s8;
       }
     }
-    // 18 x fragments: halo rows 0..5 of the row group (rr) x kw; fragment f+2 is read while fragment f's MFMAs issue
+    // 18 x fragments: halo rows 0..5 of the row group (rr) x kw; fragment f+2 is read while fragment f's MFMAs issue.
+    // The tile boundary is software-pipelined: the NEXT tile's dy fragments are read during steps 11..14 (their last use
+    // in this tile is step 11 + 3 kh... see dlast) and its x fragments 0, 1 take the read slots of steps 16, 17, so the
+    // first MFMA of tile it+1 waits for nothing but the barrier.
+    bf16x8 dnx[4];
 #pragma unroll
     for (int f = 0; f < 18; ++f) {
       const int rr = f / 3, kw = f % 3;
-      bf16x8 xq2 = xq1;
-      if (f + 2 < 18) xq2 = xfrag_at(lX, f + 2);
+      bf16x8 xq2 = f + 2 < 18 ? xfrag_at(lX, f + 2) : xfrag_at(lN + ch * C::XSUB, f + 2 - 18);
+      // dy fragment r is last used at halo row r + 2 (kh = 2), i.e. step 3 (r + 2) + 2: the next tile's fragment r is read
+      // one halo row later into its own registers (moved into dfr at the end)
+      if (kw == 0 && rr >= 2) dnx[rr - 2] = dfrag_at(lN, rr - 2);
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh) {
         const int r = rr - kh;          // halo row rr = output row r + kh
@@ -1370,7 +1374,8 @@ __global__ W6_VGPR_ATTR __launch_bounds__(512, 1) void wgrad_mfma6_kernel(W4Batc
         if (f == 11) issue_slot(ft, fs, 3);
         if (f == 14) issue_slot(ft, fs, C::NSLOT - 1);
       }
-      if (f + 2 < 18) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      if (kw == 0 && rr >= 2) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      else __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
       {
         const int nm = (rr == 0 || rr == 5) ? 1 : ((rr == 1 || rr == 4) ? 2 : 3);
         if (nm == 3) __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
@@ -1381,7 +1386,8 @@ __global__ W6_VGPR_ATTR __launch_bounds__(512, 1) void wgrad_mfma6_kernel(W4Batc
       xcur = xq1;
       xq1 = xq2;
     }
-    first_frags(ns);                     // tile it+1 (its slot was confirmed by this iteration's barrier)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dfr[r] = dnx[r];
     ps = ns;
   }
   wait_vmcnt<0>();                       // the zero-page pieces of the tiles past the end

@@ -294,6 +294,13 @@ class _DirectConv:
         self.mfma_narrow = 4 <= narrow <= 32 and wide % 32 == 0
         self.wpad = self.wp_mfma = None
         self.pack_f16 = False
+        # IMAGE side (encoder conv_in, decoder conv_out) with 2..8 image channels: both the forward launch and the
+        # gradients run on the MFMA kernels with the image channels zero-padded to one 32-wide tile (csrc/narrow_pad.hip
+        # is the boundary with the [N,C,H,W] fp32 images).  One image channel -- every shipped config -- stays on the
+        # direct kernels, which do it near their byte floors; at three channels those cost 1.65 ms more per step.
+        # Engine sets ``img_mfma`` (it knows which two convs face the image).
+        self.img_mfma = False
+        self.wp_img = self.wpt_img = self.wpad_img = self.bpad_img = None
 
     def repack(self):
         """Derived operands are written IN PLACE into buffers allocated once: captured HIP graphs (inference encode /
@@ -318,6 +325,19 @@ class _DirectConv:
             else:                       # data-gradient operand of conv_in: W'[ci(pad 32)][co]
                 self.wpad[:, :self.cin].copy_(w)
                 self.wp_mfma = ops.pack_conv_weight(self.wpad, 3, PTI_CONV_S1, flip=True, out=self.wp_mfma)
+        if self.img_mfma:
+            if self.wpad_img is None:
+                shape = (self.cout, 32, 3, 3) if self.cin < self.cout else (32, self.cin, 3, 3)
+                self.wpad_img = torch.zeros(shape, dtype=F32, device=w.device)
+                self.bpad_img = torch.zeros(32, dtype=F32, device=w.device)
+            if self.cin < self.cout:    # conv_in: forward operand W[co][ci (pad 32)]
+                self.wpad_img[:, :self.cin].copy_(w)
+                self.wp_img = ops.pack_conv_weight(self.wpad_img, 3, PTI_CONV_S1, out=self.wp_img, f16=self.pack_f16)
+            else:                       # conv_out: forward operand W[co (pad 32)][ci] and its data-gradient operand
+                self.wpad_img[:self.cout].copy_(w)
+                self.bpad_img[:self.cout].copy_(self.b.data)
+                self.wp_img = ops.pack_conv_weight(self.wpad_img, 3, PTI_CONV_S1, out=self.wp_img, f16=self.pack_f16)
+                self.wpt_img = ops.pack_conv_weight(self.wpad_img, 3, PTI_CONV_S1, flip=True, out=self.wpt_img)
 
 
 class _Plan:
@@ -399,6 +419,13 @@ class Engine:
             c.f16 = c.fwd_f16 and self.act_dtype == torch.float16
         self.direct_convs = [self.enc_in, self.enc_out, self.dec_in, self.dec_out]
         self.enc_out.pack_f16 = self.act_dtype == torch.float16     # forward launch: fp16 operands like every forward conv
+        # 2..8 image channels: conv_in / conv_out on the MFMA kernels (see _DirectConv.img_mfma); PTI_IMG_MFMA=0 keeps the
+        # direct kernels
+        img = os.environ.get("PTI_IMG_MFMA", "1") == "1"
+        self.enc_in.img_mfma = img and 2 <= net.in_channels <= 8 and net.channels[0] % 32 == 0
+        self.dec_out.img_mfma = img and 2 <= net.out_channels <= 8 and net.channels[0] % 32 == 0
+        self.enc_in.pack_f16 = self.dec_out.pack_f16 = self.act_dtype == torch.float16
+        self._wgrad_posts = []
         self.Lc = net.latent_channels
         self._plist = list(net._param_by_name.values())
 
@@ -522,19 +549,47 @@ class Engine:
             ops.wgrad_direct(wide, narrow, *args, workspace=self.workspace_side, **kw)
         self._wgrad_pending = True
 
-    def defer_wgrad(self, x, dy, dw, db):
+    def defer_wgrad(self, x, dy, dw, db, post=None):
+        """``post``: called right behind the batched launch, on its stream (the image-side convs copy the real rows /
+        columns of their zero-padded weight gradient into the gradient arena there)."""
         self._wgrad_jobs.append((x, dy, dw, db))
+        if post is not None:
+            self._wgrad_posts.append(post)
         if len(self._wgrad_jobs) >= self.wgrad_batch_max:
             self.flush_wgrad()
+
+    def wgrad_padded(self, x, dy, dw, db, post):
+        """Weight gradient of an image-side conv on its zero-padded 32-channel operands (same protocol as
+        _MfmaConv.wgrad: batched and on the side stream when those are on)."""
+        if self.batch_wgrad and ops.wgrad_batch_eligible(x, dy, 3, PTI_CONV_S1, PTI_PRO_NONE):
+            self.defer_wgrad(x, dy, dw, db, post)
+            return
+        ws = self.wgrad_stream
+        if ws is None:
+            ops.conv_wgrad_mfma(x, dy, dw, db, accumulate=True, workspace=self.workspace)
+            post()
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        ws.wait_event(ev)
+        x.record_stream(ws)
+        dy.record_stream(ws)
+        with torch.cuda.stream(ws):
+            ops.conv_wgrad_mfma(x, dy, dw, db, accumulate=True, workspace=self.workspace_side)
+            post()
+        self._wgrad_pending = True
 
     def flush_wgrad(self):
         """Launch the collected weight gradients (side stream if there is one), then hand the queued "gradients ready"
         ranges to the exchange -- in their original order, behind that launch."""
         jobs, self._wgrad_jobs = self._wgrad_jobs, []
+        posts, self._wgrad_posts = self._wgrad_posts, []
         ws = self.wgrad_stream
         if jobs:
             if ws is None:
                 ops.conv_wgrad_mfma_batched(jobs, workspace=self.workspace)
+                for p in posts:
+                    p()
             else:
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream())
@@ -544,6 +599,8 @@ class Engine:
                     dy.record_stream(ws)
                 with torch.cuda.stream(ws):
                     ops.conv_wgrad_mfma_batched(jobs, workspace=self.workspace_side)
+                    for p in posts:
+                        p()
                 self._wgrad_pending = True
         queue, self._ready_queue = self._ready_queue, []
         for rng in queue:
@@ -609,8 +666,17 @@ class Engine:
         self.begin_pass(n)
         c0 = self.net.channels[0]
         t0 = _empty((n, h, w, c0), x, self.act_dtype)
-        ops.conv_direct(x, self.enc_in.w_tck, self.enc_in.b.data, t0, n=n, h=h, w=w, cin=cin, cout=c0, x_layout="nchw")
-        a0 = _Act(t0, ops.gn_stats(t0, self.G, self.new_stats(n)))
+        xpad_b = None
+        if self.enc_in.img_mfma:   # image channels zero-padded to 32: MFMA conv with the next GroupNorm's statistics fused
+            xpad, xpad_b = ops.pad_nchw_to_nhwc32(x, self.act_dtype, BF16 if (save and self.act_dtype != BF16) else None)
+            if save and xpad_b is None:
+                xpad_b = xpad
+            st0 = self.new_stats(n)
+            ops.conv_mfma(xpad, self.enc_in.wp_img, self.enc_in.b.data, t0, cout=c0, ksize=3, out_stats=st0, out_groups=self.G)
+            a0 = _Act(t0, st0)
+        else:
+            ops.conv_direct(x, self.enc_in.w_tck, self.enc_in.b.data, t0, n=n, h=h, w=w, cin=cin, cout=c0, x_layout="nchw")
+            a0 = _Act(t0, ops.gn_stats(t0, self.G, self.new_stats(n)))
         saved = [] if save else None
         act = self._walk_fwd(self.enc_layers, a0, True, saved)
         hl, wl, L = act.t.shape[1], act.t.shape[2], self.Lc
@@ -632,11 +698,11 @@ class Engine:
         wl_, bl = self._qp("quant_conv_log_sigma")
         wp, bp = self._qp("post_quant_conv")
         ops.latent_head_fwd(hlat, None, wm, bm, wl_, bl, wp, bp, mu, sigma, None, zq_unused)
-        ctx = (x, a0, saved, act, hlat) if save else None
+        ctx = (x, a0, saved, act, hlat, xpad_b) if save else None
         return mu, sigma, ctx
 
     def encode_backward(self, ctx, dmu, dsigma, want_dx=False):
-        x, a0, saved, act, hlat = ctx
+        x, a0, saved, act, hlat, xpad_b = ctx
         net = self.net
         n, L = hlat.shape[0], self.Lc
         hl, wl = act.t.shape[1], act.t.shape[2]
@@ -670,8 +736,14 @@ class Engine:
         ei = self.enc_in
         _, cin, h, w = x.shape
         c0 = dout.shape[3]
-        self._wgrad_direct(dout, x, gv(ei.prefix + ".weight"), n=n, h=h, w=w, cw=c0, cn=cin, ksize=3, sgn=-1,
-                         narrow_layout="nchw", dw_strides=(1, cin * 9, 9), dbias_wide=gv(ei.prefix + ".bias"))
+        if ei.img_mfma:   # x = the saved zero-padded image (bf16): dW[c0][32 (pad)] -> its first cin columns
+            dwp = torch.zeros(c0, 32, 3, 3, dtype=F32, device=x.device)
+            gw = gv(ei.prefix + ".weight")
+            self.wgrad_padded(xpad_b, dout, dwp, gv(ei.prefix + ".bias"),
+                              lambda: gw.view(c0, cin, 3, 3).add_(dwp[:, :cin]))
+        else:
+            self._wgrad_direct(dout, x, gv(ei.prefix + ".weight"), n=n, h=h, w=w, cw=c0, cn=cin, ksize=3, sgn=-1,
+                               narrow_layout="nchw", dw_strides=(1, cin * 9, 9), dbias_wide=gv(ei.prefix + ".bias"))
         self._ready("encoder.blocks.0.")
         self.join_wgrad()
         if not want_dx:
@@ -698,16 +770,24 @@ class Engine:
         h, w, C = act.t.shape[1], act.t.shape[2], act.t.shape[3]
         do, nm = self.dec_out, self.dec_out.norm
         recon = _empty((n, do.cout, h, w), z, F32)
-        ops.conv_direct(act.t, do.w_tck, do.b.data, recon, n=n, h=h, w=w, cin=C, cout=do.cout, y_layout="nchw",
-                        prologue=PTI_PRO_GN, in_stats=act.stats, gamma=nm.weight.data, beta=nm.bias.data, groups=self.G,
-                        eps=self.eps)
-        ctx = (z, zq, a0, saved, act) if save else None
+        gact = None
+        if do.img_mfma:   # output channels zero-padded to 32: MFMA conv (GroupNorm in its loader; the normalised input is
+            ypad = _empty((n, h, w, 32), z, self.act_dtype)      # kept for the weight gradient), then the image slice
+            gact = _empty(act.t.shape, z) if save else None
+            ops.conv_mfma(act.t, do.wp_img, do.bpad_img, ypad, cout=32, ksize=3, prologue=PTI_PRO_GN, in_stats=act.stats,
+                          gamma=nm.weight.data, beta=nm.bias.data, groups=self.G, eps=self.eps, act_out=gact)
+            ops.slice_nhwc32_to_nchw(ypad, do.cout, out=recon)
+        else:
+            ops.conv_direct(act.t, do.w_tck, do.b.data, recon, n=n, h=h, w=w, cin=C, cout=do.cout, y_layout="nchw",
+                            prologue=PTI_PRO_GN, in_stats=act.stats, gamma=nm.weight.data, beta=nm.bias.data, groups=self.G,
+                            eps=self.eps)
+        ctx = (z, zq, a0, saved, act, gact) if save else None
         return recon, ctx
 
     def decode_backward(self, ctx, drecon, want_dz=True, join=True):
         """``join=False``: leave the side-stream weight gradients running (the caller goes on to
         ``encode_backward``, whose final join covers them: one in-order side stream)."""
-        z, zq, a0, saved, act = ctx
+        z, zq, a0, saved, act, gact = ctx
         net, gv = self.net, self.net.grad_view
         n, L, hl, wl = z.shape
         self.begin_pass(n, backward=True)
@@ -715,12 +795,24 @@ class Engine:
         do, nm = self.dec_out, self.dec_out.norm
         h, w, C = act.t.shape[1], act.t.shape[2], act.t.shape[3]
         co = do.cout
-        self._wgrad_direct(act.t, drecon, gv(do.prefix + ".weight"), n=n, h=h, w=w, cw=C, cn=co, ksize=3, sgn=1,
-                         narrow_layout="nchw", dw_strides=(1, 9, C * 9), dbias_narrow=gv(do.prefix + ".bias"),
-                         prologue=PTI_PRO_GN, in_stats=act.stats, gamma=nm.weight.data, beta=nm.bias.data, groups=self.G,
-                         eps=self.eps)
         da = _empty(act.t.shape, z)
-        ops.conv_direct(drecon, do.w_tck_t, None, da, n=n, h=h, w=w, cin=co, cout=C, x_layout="nchw")
+        if do.img_mfma:   # d recon zero-padded to 32 channels (bf16): weight gradient dW[32 (pad)][C] -> its first co rows
+            dpad, _ = ops.pad_nchw_to_nhwc32(drecon, BF16)
+            dwp = torch.zeros(32, C, 3, 3, dtype=F32, device=z.device)
+            dbp = torch.zeros(32, dtype=F32, device=z.device)
+            gw, gb = gv(do.prefix + ".weight"), gv(do.prefix + ".bias")
+
+            def post():
+                gw.view(co, C, 3, 3).add_(dwp[:co])
+                gb.add_(dbp[:co])
+            self.wgrad_padded(gact, dpad, dwp, dbp, post)
+            ops.conv_mfma(dpad, do.wpt_img, None, da, cout=C, ksize=3)
+        else:
+            self._wgrad_direct(act.t, drecon, gv(do.prefix + ".weight"), n=n, h=h, w=w, cw=C, cn=co, ksize=3, sgn=1,
+                               narrow_layout="nchw", dw_strides=(1, 9, C * 9), dbias_narrow=gv(do.prefix + ".bias"),
+                               prologue=PTI_PRO_GN, in_stats=act.stats, gamma=nm.weight.data, beta=nm.bias.data,
+                               groups=self.G, eps=self.eps)
+            ops.conv_direct(drecon, do.w_tck_t, None, da, n=n, h=h, w=w, cin=co, cout=C, x_layout="nchw")
         dout = nm.bwd(act, da, silu=False, dres=None, eng=self)
         self._ready(do.prefix[:-4], nm.prefix + ".")
         dout = self._walk_bwd(self.dec_layers, dout, saved)

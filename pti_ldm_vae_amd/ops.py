@@ -918,6 +918,31 @@ def nhwc_bf16_add_to_nchw_f32_(g, y):
     return y
 
 
+def pad_nchw_to_nhwc32(x, dtype_a, dtype_b=None):
+    """fp32 [n, c, h, w] (1 <= c <= 8) -> 16-bit [n, h, w, 32] with channels >= c zero; a second copy in ``dtype_b`` (the
+    weight gradient's bf16 operand next to the forward conv's fp16 one) comes out of the same pass."""
+    _chk(x, F32, "x", 4)
+    n, c, h, w = x.shape
+    ya = torch.empty(n, h, w, 32, dtype=dtype_a, device=x.device)
+    yb = torch.empty(n, h, w, 32, dtype=dtype_b, device=x.device) if dtype_b is not None else None
+    L.check(L.lib().pti_pad_nchw_to_nhwc32(_ptr(x), _ptr(ya), _ptr(yb), n, c, h * w, int(dtype_a == F16),
+                                           int(dtype_b == F16), _stream()), "pti_pad_nchw_to_nhwc32")
+    return ya, yb
+
+
+def slice_nhwc32_to_nchw(x, c, out=None):
+    """The first ``c`` channels of a 16-bit [n, h, w, 32] tensor -> fp32 [n, c, h, w]."""
+    _chk(x, ACT16, "x", 4)
+    n, h, w, c32 = x.shape
+    if c32 != 32:
+        raise ValueError("slice_nhwc32_to_nchw: expected 32 channels")
+    y = out if out is not None else torch.empty(n, c, h, w, dtype=F32, device=x.device)
+    _chk(y, F32, "y", 4)
+    L.check(L.lib().pti_slice_nhwc32_to_nchw(_ptr(x), _ptr(y), n, c, h * w, int(x.dtype == F16), _stream()),
+            "pti_slice_nhwc32_to_nchw")
+    return y
+
+
 def lpips_tap_nhwc_supported(c):
     return L.lib().pti_lpips_tap_nhwc_blocks(int(c), 1) > 0
 

@@ -3,7 +3,7 @@
 args=$1; shift
 for r in 1 2; do
   for cfg in "$@"; do
-    ms=$(env $cfg python bench.py --steps 20 --warmup 6 --no-cpu-baseline $args 2>/dev/null | python -c "import json,sys; print(json.loads(sys.stdin.read())['ms_per_step'])")
-    echo "round $r [$args] [$cfg] $ms ms"
+    ms=$(env $cfg python bench.py --steps 20 --warmup 6 --no-cpu-baseline $args 2>/dev/null | python -c "import json,sys; print(json.loads(sys.stdin.read())['ms_per_step'])" 2>/dev/null)
+    echo "round $r [$args] [$cfg] ${ms:-FAILED} ms"
   done
 done
