@@ -135,6 +135,23 @@ int pti_conv2d_direct(const void* x, const float* w_tck, const float* bias, cons
                       const float* gamma, const float* beta, void* y, const pti_conv_desc* d,
                       pti_stream_t s);
 
+/* Derived operands of the degenerate-channel convs (conv_in / conv_out of MONAI's Encoder / Decoder) in one launch:
+ * per entry, from the fp32 master weight w [cout][cin][3][3]:  w_tck [9][cin][cout] (forward operand of pti_conv2d_direct),
+ * w_tck_t [9][cout][cin] with the taps reversed (its data-gradient operand), wpad = the weight copied into a zero-padded
+ * master [cout'][pad_cin][3][3] (rows co < cout, columns ci < cin; the rest of the buffer is left as it is -- allocate it
+ * zeroed) that the MFMA packer reads, and bpad[0..cout) = b.  Any of the outputs may be NULL. */
+#define PTI_DIRECT_REPACK_MAX 8
+typedef struct {
+  const float* w; const float* b;
+  float* w_tck; float* w_tck_t; float* wpad; float* bpad;
+  int cout, cin, pad_cin, reserved;
+} pti_direct_repack_entry;
+typedef struct {
+  pti_direct_repack_entry e[PTI_DIRECT_REPACK_MAX];
+  int n;
+} pti_direct_repack_table;
+int pti_direct_repack(const pti_direct_repack_table* t, pti_stream_t s);
+
 /* Weight/bias gradient of pti_conv2d_direct (autograd of nn.Conv2d for the degenerate layers):
  * dw[tap*st_tap + cw*st_cw + k*st_k] += sum_p narrow[p][k] * P(wide)[p + sgn*(tap offset)][cw]
  * for every narrow channel k < cn; wide is dense NHWC bf16 with cw channels (prologue P optional),

@@ -54,6 +54,21 @@ class WgradJob(C.Structure):
 
 
 WGRAD_BATCH_MAX = 16   # PTI_WGRAD_BATCH_MAX
+DIRECT_REPACK_MAX = 8  # PTI_DIRECT_REPACK_MAX
+
+
+class DirectRepackEntry(C.Structure):
+    """``pti_direct_repack_entry`` of include/pti_vae.h."""
+
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("w_tck", C.c_void_p), ("w_tck_t", C.c_void_p), ("wpad", C.c_void_p),
+                ("bpad", C.c_void_p), ("cout", C.c_int32), ("cin", C.c_int32), ("pad_cin", C.c_int32), ("reserved", C.c_int32)]
+
+
+class DirectRepackTable(C.Structure):
+    """``pti_direct_repack_table`` of include/pti_vae.h."""
+
+    _fields_ = [("e", DirectRepackEntry * DIRECT_REPACK_MAX), ("n", C.c_int32)]
+
 
 _P = C.c_void_p
 _I = C.c_int
@@ -81,6 +96,7 @@ SIGNATURES = {
     "pti_conv_wgrad_mfma": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I, C.POINTER(ConvDesc), _P]),
     "pti_conv_wgrad_mfma_partials": (_I, [_P, _P, _P, _P, _P, _P, _I64, C.POINTER(ConvDesc), C.POINTER(_I), _P]),
     "pti_conv_wgrad_mfma_batched": (_I, [C.POINTER(WgradJob), _I, _P, _I64, _P]),
+    "pti_direct_repack": (_I, [C.POINTER(DirectRepackTable), _P]),
     "pti_conv_wgrad_reduce": (_I, [_P, _I, _P, _P, _I, C.POINTER(ConvDesc), _P]),
     "pti_gn_bwd_blocks": (_I, [_I, _I, _I]),
     "pti_gn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _P]),

@@ -522,6 +522,40 @@ static int fill_common(DArgs& a, const void* x, const float* w, const float* bia
   return 0;
 }
 
+// ---- derived operands of the degenerate-channel convs, all in ONE launch per optimiser step -----------------------------
+// (as torch ops this was three to six tiny kernels per conv at the head of every step: ~17 launches on the critical path)
+namespace {
+__global__ __launch_bounds__(256) void direct_repack_kernel(pti_direct_repack_table t) {
+  const pti_direct_repack_entry& e = t.e[blockIdx.y];
+  const int total = e.cout * e.cin * 9;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int tap = i % 9, ci = (i / 9) % e.cin, co = i / (9 * e.cin);
+    const float v = e.w[i];
+    if (e.w_tck) e.w_tck[(tap * e.cin + ci) * e.cout + co] = v;             // [tap][ci][co]
+    if (e.w_tck_t) e.w_tck_t[((8 - tap) * e.cout + co) * e.cin + ci] = v;     // data-gradient operand [8 - tap][co][ci]
+    if (e.wpad) e.wpad[(co * e.pad_cin + ci) * 9 + tap] = v;                  // zero-padded master copy [cout'][pad_cin][9]
+  }
+  if (e.bpad && blockIdx.x == 0)
+    for (int i = threadIdx.x; i < e.cout; i += 256) e.bpad[i] = e.b[i];
+}
+}  // namespace
+
+extern "C" int pti_direct_repack(const pti_direct_repack_table* t, pti_stream_t s) {
+  if (!t || t->n < 1 || t->n > PTI_DIRECT_REPACK_MAX) PTI_FAIL(PTI_EINVAL, "direct_repack: 1..%d entries", PTI_DIRECT_REPACK_MAX);
+  int most = 0;
+  for (int i = 0; i < t->n; ++i) {
+    const pti_direct_repack_entry& e = t->e[i];
+    if (!e.w || e.cout <= 0 || e.cin <= 0 || (e.wpad && e.pad_cin < e.cin) || (e.bpad && !e.b))
+      PTI_FAIL(PTI_EINVAL, "direct_repack: entry %d", i);
+    most = e.cout * e.cin * 9 > most ? e.cout * e.cin * 9 : most;
+  }
+  int blocks = (most + 255) / 256;
+  if (blocks > 64) blocks = 64;
+  PTI_LAUNCH(direct_repack_kernel, dim3(blocks, t->n), dim3(256), 0, (hipStream_t)s, *t);
+  PTI_CHECK_LAUNCH("direct_repack");
+  return PTI_OK;
+}
+
 extern "C" int pti_conv2d_direct(const void* x, const float* w, const float* bias, const int64_t* in_stats,
                                  const float* gamma, const float* beta, void* y, const pti_conv_desc* d,
                                  pti_stream_t s) {

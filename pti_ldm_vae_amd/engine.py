@@ -302,42 +302,47 @@ class _DirectConv:
         self.img_mfma = False
         self.wp_img = self.wpt_img = self.wpad_img = self.bpad_img = None
 
-    def repack(self):
-        """Derived operands are written IN PLACE into buffers allocated once: captured HIP graphs (inference encode /
-        decode, the training step) hold these addresses, so a re-pack must never move them (fresh tensors
-        per re-pack left replayed graphs reading freed memory after a native optimiser step)."""
+    def alloc(self):
+        """Buffers of the derived operands, allocated ONCE: captured HIP graphs (inference encode / decode, the training
+        step) hold these addresses, so a re-pack must never move them (fresh tensors per re-pack left replayed
+        graphs reading freed memory after a native optimiser step)."""
         w = self.w.data
-        if self.w_tck is None:
-            self.w_tck = torch.empty(9, self.cin, self.cout, dtype=F32, device=w.device)
-            self.w_tck_t = torch.empty(9, self.cout, self.cin, dtype=F32, device=w.device)
-        self.w_tck.view(3, 3, self.cin, self.cout).copy_(w.permute(2, 3, 1, 0))
-        # data-gradient operand: w'[tap'][co][ci] = w[co][ci][8 - tap']
-        self.w_tck_t.view(3, 3, self.cout, self.cin).copy_(w.flip(2, 3).permute(2, 3, 0, 1))
-        if self.mfma_narrow:
-            if self.wpad is None:   # narrow channels padded to 32: [32, wide, 3, 3] (conv_out) or [wide, 32, 3, 3] (conv_in)
-                shape = (32, self.cin, 3, 3) if self.cout < self.cin else (self.cout, 32, 3, 3)
-                self.wpad = torch.zeros(shape, dtype=F32, device=w.device)
-                self.bpad = torch.zeros(32, dtype=F32, device=w.device)
-            if self.cout < self.cin:    # forward operand of conv_out (fp16 when the forward pass runs fp16 operands)
-                self.wpad[:self.cout].copy_(w)
-                self.bpad[:self.cout].copy_(self.b.data)
-                self.wp_mfma = ops.pack_conv_weight(self.wpad, 3, PTI_CONV_S1, out=self.wp_mfma, f16=self.pack_f16)
-            else:                       # data-gradient operand of conv_in: W'[ci(pad 32)][co]
-                self.wpad[:, :self.cin].copy_(w)
-                self.wp_mfma = ops.pack_conv_weight(self.wpad, 3, PTI_CONV_S1, flip=True, out=self.wp_mfma)
+        if self.w_tck is not None:
+            return
+        self.w_tck = torch.empty(9, self.cin, self.cout, dtype=F32, device=w.device)
+        self.w_tck_t = torch.empty(9, self.cout, self.cin, dtype=F32, device=w.device)
+        if self.mfma_narrow:   # narrow channels padded to 32: [32, wide, 3, 3] (conv_out) or [wide, 32, 3, 3] (conv_in)
+            shape = (32, self.cin, 3, 3) if self.cout < self.cin else (self.cout, 32, 3, 3)
+            self.wpad = torch.zeros(shape, dtype=F32, device=w.device)
+            self.bpad = torch.zeros(32, dtype=F32, device=w.device)
         if self.img_mfma:
-            if self.wpad_img is None:
-                shape = (self.cout, 32, 3, 3) if self.cin < self.cout else (32, self.cin, 3, 3)
-                self.wpad_img = torch.zeros(shape, dtype=F32, device=w.device)
-                self.bpad_img = torch.zeros(32, dtype=F32, device=w.device)
-            if self.cin < self.cout:    # conv_in: forward operand W[co][ci (pad 32)]
-                self.wpad_img[:, :self.cin].copy_(w)
-                self.wp_img = ops.pack_conv_weight(self.wpad_img, 3, PTI_CONV_S1, out=self.wp_img, f16=self.pack_f16)
-            else:                       # conv_out: forward operand W[co (pad 32)][ci] and its data-gradient operand
-                self.wpad_img[:self.cout].copy_(w)
-                self.bpad_img[:self.cout].copy_(self.b.data)
-                self.wp_img = ops.pack_conv_weight(self.wpad_img, 3, PTI_CONV_S1, out=self.wp_img, f16=self.pack_f16)
-                self.wpt_img = ops.pack_conv_weight(self.wpad_img, 3, PTI_CONV_S1, flip=True, out=self.wpt_img)
+            shape = (self.cout, 32, 3, 3) if self.cin < self.cout else (32, self.cin, 3, 3)
+            self.wpad_img = torch.zeros(shape, dtype=F32, device=w.device)
+            self.bpad_img = torch.zeros(32, dtype=F32, device=w.device)
+
+    def repack_entries(self):
+        """Entries of the one-launch re-pack (ops.DirectRepack): w -> w_tck, its tap-reversed transpose (the
+        data-gradient operand w'[tap'][co][ci] = w[co][ci][8 - tap']) and the zero-padded master copies."""
+        w, b = self.w.data, self.b.data
+        out = [dict(w=w, b=b, w_tck=self.w_tck, w_tck_t=self.w_tck_t,
+                    wpad=self.wpad, bpad=self.bpad if (self.mfma_narrow and self.cout < self.cin) else None)]
+        if self.img_mfma:
+            out.append(dict(w=w, b=b, wpad=self.wpad_img, bpad=self.bpad_img if self.cout < self.cin else None))
+        return out
+
+    def pack_entries(self):
+        """(attribute, BatchedPacker entry) of the MFMA operands packed from the zero-padded master copies."""
+        out = []
+        if self.mfma_narrow:
+            if self.cout < self.cin:    # forward operand of conv_out (fp16 when the forward pass runs fp16 operands)
+                out.append(("wp_mfma", (self.wpad, 3, PTI_CONV_S1, False, self.pack_f16)))
+            else:                       # data-gradient operand of conv_in: W'[ci(pad 32)][co]
+                out.append(("wp_mfma", (self.wpad, 3, PTI_CONV_S1, True, False)))
+        if self.img_mfma:
+            out.append(("wp_img", (self.wpad_img, 3, PTI_CONV_S1, False, self.pack_f16)))
+            if self.cout < self.cin:    # conv_out: its data-gradient operand as well
+                out.append(("wpt_img", (self.wpad_img, 3, PTI_CONV_S1, True, False)))
+        return out
 
 
 class _Plan:
@@ -471,7 +476,7 @@ class Engine:
         """Addresses of every derived weight operand a captured inference graph reads."""
         ids = [t.data_ptr() for c in self.mfma_convs for t in (c.wp, c.wpt) if t is not None]
         for c in self.direct_convs:
-            ids += [t.data_ptr() for t in (c.w_tck, c.w_tck_t, c.wp_mfma, c.wpad) if t is not None]
+            ids += [t.data_ptr() for t in (c.w_tck, c.w_tck_t, c.wp_mfma, c.wpad, c.wp_img, c.wpt_img, c.wpad_img) if t is not None]
         return tuple(ids)
 
     def _drop_stale_graphs(self):
@@ -497,12 +502,23 @@ class Engine:
             for c in self.mfma_convs:
                 dmode = PTI_CONV_ZINS if c.mode == PTI_CONV_S2PAD else PTI_CONV_S1
                 entries += [(c._w(), c.ksize, c.mode, False, c.f16), (c._w(), c.ksize, dmode, True, False)]
+            # the degenerate-channel convs: one launch for their fp32 operands / zero-padded master copies
+            # (ops.DirectRepack), and their MFMA operands ride the batched pack launch below
+            rep, targets = [], []
+            for c in self.direct_convs:
+                c.alloc()
+                rep += c.repack_entries()
+                for attr, e in c.pack_entries():
+                    targets.append((c, attr, len(entries)))
+                    entries.append(e)
+            self._direct_repack = ops.DirectRepack(rep)
             self._packer = ops.BatchedPacker(entries, self.dev)
             for i, c in enumerate(self.mfma_convs):
                 c.wp, c.wpt = self._packer.outputs[2 * i], self._packer.outputs[2 * i + 1]
+            for c, attr, i in targets:
+                setattr(c, attr, self._packer.outputs[i])
+        self._direct_repack.run()     # (before the pack launch: it fills the padded copies that launch reads)
         self._packer.run()
-        for c in self.direct_convs:
-            c.repack()
         self.packed_version = v
         self.pack_gen += 1
 

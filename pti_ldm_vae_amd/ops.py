@@ -82,6 +82,45 @@ def pack_conv_weight(ws, ksize, mode=PTI_CONV_S1, flip=False, out=None, f16=Fals
     return out
 
 
+class DirectRepack:
+    """The derived operands of up to DIRECT_REPACK_MAX degenerate-channel convs as ONE launch (csrc/conv_direct.hip,
+    ``pti_direct_repack``).  ``entries``: dicts with w (fp32 [cout,cin,3,3]) and optionally b, w_tck, w_tck_t, wpad (zeroed
+    fp32 [cout', pad_cin, 3, 3], cout' >= cout), bpad.  Every tensor lives at a fixed address (parameter arena views /
+    buffers allocated once), so the table is built once."""
+
+    def __init__(self, entries):
+        if not 1 <= len(entries) <= L.DIRECT_REPACK_MAX:
+            raise ValueError(f"DirectRepack: 1..{L.DIRECT_REPACK_MAX} entries")
+        self.table = L.DirectRepackTable()
+        self.table.n = len(entries)
+        self._keep = entries
+        for i, e in enumerate(entries):
+            w = e["w"]
+            _chk(w, F32, "w", 4)
+            cout, cin = w.shape[0], w.shape[1]
+            if w.shape[2] != 3 or w.shape[3] != 3:
+                raise ValueError("DirectRepack: 3x3 weights")
+            for k in ("b", "w_tck", "w_tck_t", "wpad", "bpad"):
+                if e.get(k) is not None:
+                    _chk(e[k], F32, k)
+            wpad = e.get("wpad")
+            pad_cin = 0
+            if wpad is not None:
+                pad_cin = wpad.shape[1]
+                if wpad.dim() != 4 or wpad.shape[0] < cout or pad_cin < cin or wpad.shape[2:] != w.shape[2:]:
+                    raise ValueError("DirectRepack: wpad shape")
+            for k, size in (("w_tck", cout * cin * 9), ("w_tck_t", cout * cin * 9), ("bpad", cout)):
+                if e.get(k) is not None and e[k].numel() < size:
+                    raise ValueError(f"DirectRepack: {k} too small")
+            if e.get("bpad") is not None and (e.get("b") is None or e["b"].numel() != cout):
+                raise ValueError("DirectRepack: bpad needs b")
+            self.table.e[i] = L.DirectRepackEntry(_ptr(w), _ptr(e.get("b")), _ptr(e.get("w_tck")), _ptr(e.get("w_tck_t")),
+                                                  _ptr(wpad), _ptr(e.get("bpad")), cout, cin, pad_cin, 0)
+
+    def run(self):
+        L.check(L.lib().pti_direct_repack(C.byref(self.table), _stream()), "pti_direct_repack")
+
+
 def _chk_stats(t, count, name):
     _chk(t, I64, name)
     if t.numel() != count:

@@ -149,4 +149,5 @@ def test_bench_two_gpu_line_from_the_drivers_launch_command(dev, dp_job):
     assert d["scaling"] == "weak" and d["steps"] == 3 and d["warmup"] == 3 and d["value"] > 0 and d["ms_per_step"] > 0
     assert "cpu_baseline" not in d                               # rank 0 at N = 1 only
     # (which family tops the instrumented steps is not asserted: at batch 2 with both ranks sharing one GPU it varies)
-    assert d["roofline"] and isinstance(d["roofline"]["kernel"], str) and d["roofline"]["frac"] > 0
+    # nor is its fraction (two processes time-slicing one GPU: launches of tens of milliseconds, frac rounds to 0)
+    assert d["roofline"] and isinstance(d["roofline"]["kernel"], str) and d["roofline"]["frac"] >= 0
