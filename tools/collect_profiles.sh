@@ -18,7 +18,7 @@ python3 "$root/tools/pmc_traffic.py" "$out/pmc_fetch" "$out/pmc_write" "$out/${t
 cp "$(find "$out/trace" -name '*kernel_stats.csv' | head -1)" "$out/${tag}_bench_b32_kernel_stats.csv"
 echo "== pipe counters per conv shape"
 CNT="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"
-for spec in "32 32 256 256 0 full" "32 32 256 256 0 dgrad" "64 64 128 128 0 full" "64 64 128 128 0 dgrad" "128 128 64 64 0 full" "128 128 64 64 0 dgrad" "128 128 32 32 0 full" "128 128 32 32 0 dgrad" "128 128 128 128 0 plain"; do
+for spec in "32 32 256 256 0 full" "32 32 256 256 0 dgrad" "64 64 128 128 0 full" "64 64 128 128 0 dgrad" "128 128 64 64 0 full" "128 128 64 64 0 dgrad" "128 128 32 32 0 full" "128 128 32 32 0 dgrad" "128 128 128 128 0 plain" "128 128 128 128 0 wgrad" "128 128 64 64 0 wgrad" "64 64 128 128 0 wgrad" "32 32 256 256 0 wgrad"; do
   name=$(echo $spec | tr ' ' '_')
   rocprofv3 --pmc $CNT --kernel-trace -d "$out/pipes_$name" --output-format csv -- python3 "$root/tools/pmc_conv.py" $spec > /dev/null 2> "$out/pipes_$name.err" || echo "pipes $spec failed"
 done

@@ -27,7 +27,7 @@ for d in sorted(glob.glob(os.path.join(out, "pipes_*"))):
     cnt = collections.Counter()
     for row in csv.DictReader(open(cc[0])):
         k = row["Kernel_Name"]
-        if "conv_mfma" not in k:
+        if "conv_mfma" not in k and "wgrad_mfma" not in k:
             continue
         acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
         if row["Counter_Name"] == "SQ_WAVE_CYCLES":
@@ -36,7 +36,7 @@ for d in sorted(glob.glob(os.path.join(out, "pipes_*"))):
     grid = {}
     for row in csv.DictReader(open(kt[0])):
         k = row["Kernel_Name"]
-        if "conv_mfma" in k:
+        if "conv_mfma" in k or "wgrad_mfma" in k:
             dur[k].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
             grid[k] = int(row["Grid_Size_X"]) * int(row["Grid_Size_Y"]) // 64
     spec = os.path.basename(d)[6:].split("_")

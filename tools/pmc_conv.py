@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Launch one MFMA conv shape a few times (for `rocprofv3 --pmc ... -- python3 tools/pmc_conv.py cin cout h w [mode] [variant]`).
 variant: plain | gn | full (GN+SiLU prologue, residual, fused stats, activated-input side output = the training step's
-forward launch) | dgrad (data gradient fused with the GroupNorm+SiLU backward reduction).
+forward launch) | dgrad (data gradient fused with the GroupNorm+SiLU backward reduction) | wgrad (weight gradient of the
+plain stride-1 conv on bf16 operands: the kernel the library picks for the shape -- v6 / v4 -- plus its slab reduction).
 PMC_ACT=fp16 (default): x / y / residual stored fp16 and fp16-packed weights = the training step's forward format;
 PMC_ACT=bf16: all-bf16 storage and operands."""
 import os
@@ -20,7 +21,13 @@ f16 = os.environ.get("PMC_ACT", "fp16") == "fp16"
 ADT = torch.float16 if f16 else torch.bfloat16
 x = (torch.randn(B, h, w, cin, device=dev) * 1.3).to(ADT)
 wt = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
-if variant == "dgrad":
+if variant == "wgrad":
+    xb = x.to(torch.bfloat16)
+    dy = torch.randn(B, h, w, cout, device=dev).to(torch.bfloat16)
+    dw, db = torch.zeros(cout, cin, 3, 3, device=dev), torch.zeros(cout, device=dev)
+    for _ in range(5):
+        ops.conv_wgrad_mfma(xb, dy, dw, db)
+elif variant == "dgrad":
     dy = torch.randn(B, h, w, cout, device=dev).to(torch.bfloat16)
     wpt = ops.pack_conv_weight(wt, 3, ops.PTI_CONV_S1, flip=True)
     st = ops.gn_stats(x, G)
