@@ -256,3 +256,55 @@ def test_conv_wgrad_mfma_batched(dev):
         ops.conv_wgrad_mfma_batched([])
     with pytest.raises(ValueError):
         ops.conv_wgrad_mfma_batched(jobs * 3)
+
+
+def test_image_pad_and_slice_kernels(dev):
+    """csrc/narrow_pad.hip: [N,C,H,W] fp32 -> zero-padded 32-channel NHWC 16-bit copies (one pass, two formats) and the
+    slice back; both against plain torch indexing (bit-exact: the only arithmetic is the 16-bit rounding torch also does)."""
+    from pti_ldm_vae_amd import ops
+    for n, c, h, w in [(2, 3, 8, 16), (3, 1, 5, 7), (1, 8, 4, 4), (2, 2, 33, 17)]:
+        x = torch.randn(n, c, h, w, device=dev)
+        ya, yb = ops.pad_nchw_to_nhwc32(x, torch.float16, torch.bfloat16)
+        ref = torch.zeros(n, h, w, 32, device=dev)
+        ref[..., :c] = x.permute(0, 2, 3, 1)
+        assert torch.equal(ya, ref.half()) and torch.equal(yb, ref.bfloat16())
+        y1, none = ops.pad_nchw_to_nhwc32(x, torch.bfloat16)
+        assert none is None and torch.equal(y1, ref.bfloat16())
+        t = torch.randn(n, h, w, 32, device=dev).half()
+        assert torch.equal(ops.slice_nhwc32_to_nchw(t, c), t[..., :c].permute(0, 3, 1, 2).float().contiguous())
+        tb = t.bfloat16()
+        assert torch.equal(ops.slice_nhwc32_to_nchw(tb, c), tb[..., :c].permute(0, 3, 1, 2).float().contiguous())
+    with pytest.raises(Exception):
+        ops.pad_nchw_to_nhwc32(torch.randn(1, 9, 4, 4, device=dev), torch.float16)     # more than 8 image channels
+
+
+def test_direct_repack_one_launch(dev):
+    """pti_direct_repack: the degenerate-channel convs' operands from the fp32 master weight -- [tap][ci][co], the
+    tap-reversed [tap][co][ci] of the data gradient, and the zero-padded master copies the MFMA packer reads -- against
+    torch permutes, several entries of different shapes in one launch."""
+    from pti_ldm_vae_amd import ops
+    ents, refs = [], []
+    for cout, cin, pad in [(32, 1, None), (4, 128, "rows"), (128, 4, "cols"), (3, 32, "rows"), (32, 3, "cols")]:
+        w = torch.randn(cout, cin, 3, 3, device=dev)
+        b = torch.randn(cout, device=dev)
+        e = dict(w=w, b=b, w_tck=torch.empty(9, cin, cout, device=dev), w_tck_t=torch.empty(9, cout, cin, device=dev))
+        if pad == "rows":
+            e["wpad"], e["bpad"] = torch.zeros(32, cin, 3, 3, device=dev), torch.zeros(32, device=dev)
+        elif pad == "cols":
+            e["wpad"] = torch.zeros(cout, 32, 3, 3, device=dev)
+        ents.append(e)
+        refs.append((w.permute(2, 3, 1, 0).reshape(9, cin, cout), w.flip(2, 3).permute(2, 3, 0, 1).reshape(9, cout, cin)))
+    rp = ops.DirectRepack(ents)
+    rp.run()
+    torch.cuda.synchronize()
+    for e, (r1, r2) in zip(ents, refs):
+        assert torch.equal(e["w_tck"], r1) and torch.equal(e["w_tck_t"], r2)
+        w = e["w"]
+        if "wpad" in e:
+            ref = torch.zeros_like(e["wpad"])
+            ref[:w.shape[0], :w.shape[1]] = w
+            assert torch.equal(e["wpad"], ref)
+        if "bpad" in e:
+            assert torch.equal(e["bpad"][:w.shape[0]], e["b"]) and float(e["bpad"][w.shape[0]:].abs().sum()) == 0.0
+    with pytest.raises(ValueError):
+        ops.DirectRepack([dict(w=torch.randn(4, 4, 3, 3, device=dev), wpad=torch.zeros(2, 4, 3, 3, device=dev))])
