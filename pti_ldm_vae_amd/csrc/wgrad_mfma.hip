@@ -1553,17 +1553,20 @@ void launch_wt(const WgArgs& a, int co_t, int ci_t, int grid_y, hipStream_t st) 
 // Kernel mode of a job (W4Job::cob2): 0 = pairs of tiles, 32co x 32ci per workgroup; 1 = two output-channel blocks per
 // workgroup (Cout % 64 == 0); the v6 kernel: 2 = shape A, 128co x 64ci per workgroup on 4 x 16-pixel tiles (Cout % 128 ==
 // 0 and Cin % 64 == 0), 3 = shape B, 64co x 64ci on 8 x 16-pixel tiles (Cout % 64 == 0 and Cin % 64 == 0).
-// PTI_WGRAD_V6 (read per call: the A/B tool toggles it inside one process): 0 = never, 1 = shape A only (the default),
-// 2 = A and B.  Shape B is 20-28 % faster than v4's two-block mode launch for launch (64->64@128^2 80 -> 57 us,
-// @256^2 216 -> 166 us = 933 TFLOP/s) and still costs the training step of config A +0.15 ms when it replaces it (same
-// box, interleaved, three runs; with a 160-KiB or a 120-KiB ring, 512 to 2048 workgroups): its jobs -- the 64-channel
-// layers' weight gradients -- run beside the HBM-bound 32-channel data-gradient chain on the other stream, and the
-// faster kernel takes bandwidth from that critical path.  Kept selectable; not the default.
-static int w6_mode(int cin, int cout) {
+// PTI_WGRAD_V6 (read per call: the A/B tool toggles it inside one process): 0 = never, 1 = shape A only, 2 = A and B
+// wherever they fit, 3 (the default) = A, and B for layers on maps of at most 128 x 128 pixels.
+// Shape B is 20-28 % faster than v4's two-block mode launch for launch (64->64@128^2 80 -> 57 us, @256^2 216 -> 166 us =
+// 933 TFLOP/s).  Inside the training step (same-box interleaved A/Bs, final kernels, 256-MB workspace) it is worth
+// -0.7..0.9 % on config A (its 64-channel layers sit at 128^2) and -1.1 % with three image channels, and COSTS +2..3.5 %
+// on the AR model at batch 8 and 32, whose 64-channel layers are its FIRST level (256^2): those jobs run beside the
+// HBM-bound first-level data-gradient chain on the other stream (and launch for launch B wins there too, 78 -> 56 us at
+// batch 8), so the faster kernel takes bandwidth from the critical path.  Hence the map-size rule.  (With round 2's
+// 48-MB workspace split three ways, B lost on config A as well.)
+static int w6_mode(int n, int h, int w, int cin, int cout) {
   const char* e = getenv("PTI_WGRAD_V6");
-  const int v = e ? atoi(e) : 1;
+  const int v = e ? atoi(e) : 3;
   if (v >= 1 && cout % 128 == 0 && cin % 64 == 0) return 2;
-  if (v >= 2 && cout % 64 == 0 && cin % 64 == 0) return 3;
+  if (v >= 2 && cout % 64 == 0 && cin % 64 == 0 && (v == 2 || (long long)h * w <= 128 * 128)) return 3;
   return 0;
 }
 static void w4_fill_job(W4Job& a, const void* x, const void* dy, int n, int h, int w, int cin, int cout, int v6 = 0) {
@@ -1745,7 +1748,7 @@ extern "C" int pti_conv_wgrad_mfma_partials(const void* x, const void* dy, const
   if (v4) {
     W4Batch b;
     b.njobs = 1;
-    w4_fill_job(b.job[0], x, dy, d->n, d->h, d->w, d->cin, d->cout, w6_mode(d->cin, d->cout));
+    w4_fill_job(b.job[0], x, dy, d->n, d->h, d->w, d->cin, d->cout, w6_mode(d->n, d->h, d->w, d->cin, d->cout));
     b.dw[0] = b.dbias[0] = nullptr;
     b.accumulate[0] = 0;
     if (w4_plan(b, (float*)workspace, workspace_bytes / 4) < 0)
@@ -1824,7 +1827,7 @@ extern "C" int pti_conv_wgrad_mfma_batched(const pti_wgrad_job* jobs, int njobs,
       PTI_FAIL(PTI_EUNSUPPORTED, "conv_wgrad_mfma_batched: job %d: n=%d h=%d w=%d cin=%d cout=%d (channels must be multiples of 32, tensors < 2 GiB)",
                j, q.n, q.h, q.w, q.cin, q.cout);
     W4Job jb;
-    w4_fill_job(jb, q.x, q.dy, q.n, q.h, q.w, q.cin, q.cout, w6_mode(q.cin, q.cout));
+    w4_fill_job(jb, q.x, q.dy, q.n, q.h, q.w, q.cin, q.cout, w6_mode(q.n, q.h, q.w, q.cin, q.cout));
     W4Batch& b = bm[jb.cob2];
     const int k = b.njobs++;
     b.job[k] = jb;

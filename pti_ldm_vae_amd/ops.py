@@ -388,17 +388,18 @@ def conv_wgrad_mfma_batched(jobs, workspace=None, accumulate=True):
     # so that each kernel gets its own record (its own algorithmic work, its own duration = partial launch + the <1 %
     # reduction launch) under its own name
     cob2 = os.environ.get("PTI_WGRAD_V4_COB2", "1") != "0"
-    v6 = int(os.environ.get("PTI_WGRAD_V6", "1") or 0)
+    v6 = int(os.environ.get("PTI_WGRAD_V6", "3") or 0)
 
-    def mode_of(cin, cout):
+    def mode_of(x, cout):
+        cin = x.shape[3]
         if v6 >= 1 and cout % 128 == 0 and cin % 64 == 0:
             return 2
-        if v6 >= 2 and cout % 64 == 0 and cin % 64 == 0:
+        if v6 >= 2 and cout % 64 == 0 and cin % 64 == 0 and (v6 == 2 or x.shape[1] * x.shape[2] <= 128 * 128):
             return 3
         return 1 if cob2 and cout % 64 == 0 else 0
     groups = {}
     for i, (x, dy, dw, db) in enumerate(jobs):
-        groups.setdefault(mode_of(x.shape[3], dy.shape[3]), []).append(i)
+        groups.setdefault(mode_of(x, dy.shape[3]), []).append(i)
     for mode in (3, 2, 1, 0):
         idx = groups.get(mode)
         if not idx:
