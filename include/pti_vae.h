@@ -221,6 +221,22 @@ int pti_gn_bwd(const void* x, const void* da, const void* dres, void* dx, const 
  * pti_gn_sums_finalize(gpartials, sums, n, tiles, 2*cout) adds the tile rows up into sums[n][c][2];
  * pti_gn_bwd_apply then finishes dx = rstd*(gamma*dy - c1 - xhat*c2) [+ dres] and dgamma / dbeta +=.           */
 int pti_conv_gnbwd_tiles(const pti_conv_desc* d);
+/* Chained form (SURVEY 2.1 K4 "GroupNorm backward folded into the consumer's loader"): the launch's INPUT is not a
+ * materialised gradient but the pair (g_in = dA * act'(GN(x_in)), x_in) of the GroupNorm ABOVE with its statistics,
+ * weight and finalized sums {sum g, sum g*xhat} per (n, channel); the loader stages
+ * rstd * (gamma * g - c1 - xhat * c2) -- what pti_gn_bwd_apply would have written -- and also writes it to dx_in_out
+ * (bf16, same shape) for the weight gradient of the conv in between.  Everything else as pti_conv2d_mfma_gnbwd.
+ * pti_conv_gnbwd_chain_supported(cin, cout, ksize): 3x3 with cin and cout multiples of 128.  The affine gradients of the
+ * chained GroupNorm come from pti_gn_affine_grads (dgamma[c] += sum_n sums[n][c][1], dbeta[c] += sum_n sums[n][c][0]). */
+int pti_conv_gnbwd_chain_supported(int cin, int cout, int ksize);
+int pti_conv2d_mfma_gnbwd_chain(const void* g_in, const void* x_in, int x_in_f16, const int64_t* in_stats,
+                                const float* in_gamma, const float* in_sums, void* dx_in_out, const void* w_packed,
+                                const void* gx, const int64_t* gstats, const float* ggamma, const float* gbeta,
+                                void* dy_out, float* gsums, const pti_conv_desc* d, int silu, pti_stream_t s);
+int pti_gn_affine_grads(const float* sums, float* dgamma, float* dbeta, int n, int c, pti_stream_t s);
+/* pti_gn_sums_finalize with pti_gn_affine_grads(affine_sums, dgamma, dbeta, n, affine_c) riding in the same launch */
+int pti_gn_sums_finalize_affine(const float* partials, float* sums, int n, int tiles, int row_len, const float* affine_sums,
+                                float* dgamma, float* dbeta, int affine_c, pti_stream_t s);
 int pti_conv2d_mfma_gnbwd(const void* dy_in, const void* w_packed, const void* gx, const int64_t* gstats,
                           const float* ggamma, const float* gbeta, void* dy_out, float* gpartials,
                           const pti_conv_desc* d, int silu, pti_stream_t s);

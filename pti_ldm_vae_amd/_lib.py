@@ -103,6 +103,10 @@ SIGNATURES = {
     "pti_conv_gnbwd_tiles": (_I, [C.POINTER(ConvDesc)]),
     "pti_gn_sums_finalize": (_I, [_P, _P, _I, _I, _I, _P]),
     "pti_conv2d_mfma_gnbwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(ConvDesc), _I, _P]),
+    "pti_conv_gnbwd_chain_supported": (_I, [_I, _I, _I]),
+    "pti_conv2d_mfma_gnbwd_chain": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(ConvDesc), _I, _P]),
+    "pti_gn_affine_grads": (_I, [_P, _P, _P, _I, _I, _P]),
+    "pti_gn_sums_finalize_affine": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _I, _P]),
     "pti_gn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
     "pti_pool2x2_sum": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "pti_attention_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),

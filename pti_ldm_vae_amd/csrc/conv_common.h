@@ -35,7 +35,14 @@ struct ConvArgs {
   int pool2;   // v2 kernel: store the 2x2-sum-pooled output tile [N][Ho/2][Wo/2][Cout] (data gradient of nearest-2x up-sampling)
   int relu_out;   // y = max(y, 0) in the epilogue (plain fp16 forward launches only: the perceptual network's Fire convs)
   int w_f16;   // packed weights are IEEE fp16 and the MFMA runs v_mfma_f32_32x32x16_f16 on fp16 operands (forward convs on fp16 storage)
+  // prologue PRO_GNB (the GroupNorm backward of the layer ABOVE, applied while the input is staged): x = g = dA * act'(GN(x2)),
+  // x2 = that GroupNorm's input, in_stats / gamma = its statistics / weight, p_sums = its finalized {sum g, sum g*xhat}
+  // per (n, channel); the staged value is  rstd * (gamma * g - c1 - xhat * c2)
+  const bf16* x2;
+  const float* p_sums;
+  int x2_f16;
 };
+constexpr int PRO_GNB = 3;   // (internal: not a PTI_PRO_* value of the C-ABI's pti_conv_desc)
 
 // One 32x32x16 MFMA step on bf16 or (OPH) fp16 operands; the fragment registers are typed bf16x8 either way.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));

@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
   // 2*G threads convert the fixed-point values once instead of every thread converting the ones its channels need
   // (256 B behind the 1-KiB accumulator area, so groups <= 32)
   float* sfl = reinterpret_cast<float*>(smem + C::STAT_OFF + 1024);
-  if (prologue != PTI_PRO_NONE) {
+  if (prologue == PTI_PRO_GN || prologue == PTI_PRO_GN_SILU) {
     if (tid < 2 * a.groups) sfl[tid] = stat_f(a.in_stats, n * a.groups * 2 + tid);
   } else if (gn_on) {
     if (tid < 2 * a.g_groups) sfl[tid] = stat_f(a.g_stats, n * a.g_groups * 2 + tid);
@@ -459,7 +459,9 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
         dst[u] = *(const bf16x8*)(wlane + (size_t)kb * C::NT * 1024);
       }
     };
-    if constexpr (!(SAVE && PXF == 2)) wload(wa, 0);   // (side-output variant at the 128-VGPR cap: after staging)
+    // (side-output variant at the 128-VGPR cap, and the two-input prologue with its second set of staging registers: after staging)
+    constexpr bool WLATE = (SAVE && PXF == 2) || PRO == PRO_GNB;
+    if constexpr (!WLATE) wload(wa, 0);
 
     // Halo loads through a buffer descriptor with 32-bit byte offsets: an out-of-image (or zero-inserted, or
     // past-the-tile) piece gets an offset beyond the descriptor's range and the hardware returns zeros -- no
@@ -467,10 +469,13 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
     // 18 of them quarter-rate v_mad_u64_u32, on kernels that are VALU-bound: ~1/5 of a narrow-layer tile's VALU work).
     // The host guarantees x has fewer than 2^31 bytes.
     u32x4 raw[C::HITERS];
+    u32x4 raw2[PRO == PRO_GNB ? C::HITERS : 1];     // PRO_GNB: the same pieces of the second input (the GroupNorm input)
     bool ok[C::HITERS];
     {
       const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<bf16*>(a.x), 0, (unsigned)a.N * (unsigned)a.H * (unsigned)a.W * (unsigned)a.Cin * 2u, 0x00020000);
+      const __amdgpu_buffer_rsrc_t x2rs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<bf16*>(PRO == PRO_GNB ? a.x2 : a.x), 0, (unsigned)a.N * (unsigned)a.H * (unsigned)a.W * (unsigned)a.Cin * 2u, 0x00020000);
       const unsigned base = ((unsigned)n * a.H * a.W * a.Cin + chunk * CK + lc * 8) * 2u;   // sample + channel piece
       const unsigned rowb = (unsigned)a.W * a.Cin * 2u, pixb = (unsigned)a.Cin * 2u;
 #pragma unroll
@@ -488,13 +493,34 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
         ok[it] = v;
         const unsigned off = v ? base + (unsigned)iy * rowb + (unsigned)ix * pixb : 0x80000000u;
         raw[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0));
+        if constexpr (PRO == PRO_GNB) raw2[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(x2rs, off, 0, 0));
       }
     }
     // GroupNorm scale / shift of this thread's 8 channels: fetched AFTER the halo loads were issued, so that the
     // statistics / gamma / beta round trips (L2) overlap the halo's HBM round trip instead of preceding it
     if (chunk == 0) __syncthreads();   // the float statistics table (sfl) is complete
     float sc[8], sh[8];
-    if (prologue != PTI_PRO_NONE) {
+    [[maybe_unused]] float gnb_b = 0.f, gnb_d = 0.f;
+    if constexpr (PRO == PRO_GNB) {
+      // staged value = rstd*(gamma*g - c1 - xhat*c2) = sc[j]*g + gnb_b*h + gnb_d with xhat = (h - mean)*rstd and, per
+      // (sample, group), c1 = mean_c(gamma*sum g), c2 = mean_c(gamma*sum g*xhat) over the group's channels x pixels.
+      // One 8-channel piece lies inside one group (channels per group >= 8); a wider group is walked.
+      const int ch0 = chunk * CK + lc * 8, g = ch0 / cpg;
+      const float mean = stat_f(a.in_stats, (n * a.groups + g) * 2) * a.inv_cnt;
+      const float rstd = rsqrtf(fmaxf(stat_f(a.in_stats, (n * a.groups + g) * 2 + 1) * a.inv_cnt - mean * mean, 0.f) + a.eps);
+      float t1 = 0.f, t2 = 0.f;
+      for (int cc = g * cpg; cc < (g + 1) * cpg; ++cc) {
+        const f32x2 sv = *(const f32x2*)(a.p_sums + ((size_t)n * a.Cin + cc) * 2);
+        const float gm = a.gamma[cc];
+        t1 += gm * sv[0];
+        t2 += gm * sv[1];
+      }
+      const float c1 = t1 * a.inv_cnt, c2 = t2 * a.inv_cnt;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sc[j] = rstd * a.gamma[ch0 + j];
+      gnb_b = -rstd * rstd * c2;
+      gnb_d = -rstd * c1 - gnb_b * mean;
+    } else if (prologue != PTI_PRO_NONE) {
       // per GROUP on a straight-line path per group size (shift for the group index, one v_rsq per group): the
       // per-channel form -- integer division by the run-time channels-per-group and a guarded rsqrtf per channel --
       // cost ~25 VALU instructions per channel on kernels that are VALU-bound
@@ -508,7 +534,16 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
       if (p < C::NP) {
         const int hy = p / C::HW, hx = p - hy * C::HW;
         u32x4 r = raw[it];
-        if (prologue != PTI_PRO_NONE && ok[it]) {
+        if constexpr (PRO == PRO_GNB) {
+          if (ok[it]) {
+            float f[8], h[8];
+            unpack8(r, f);
+            unpack8f(raw2[it], h, a.x2_f16 != 0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = fmaf(sc[j], f[j], fmaf(gnb_b, h[j], gnb_d));
+            r = pack8(f);
+          }
+        } else if (prologue != PTI_PRO_NONE && ok[it]) {
           float f[8];
           unpack8f(r, f, in_f16);
           if (PXF == 4 && prologue == PTI_PRO_GN_SILU) {
@@ -570,7 +605,7 @@ __global__ __launch_bounds__(256, (PXF == 2 ? 4 : 2)) void conv_mfma2_kernel(Con
       }
     }
 
-    if constexpr (SAVE && PXF == 2) wload(wa, 0);
+    if constexpr (WLATE) wload(wa, 0);
     // main loop over groups of R k-blocks.  B (pixel) fragments are double-buffered in registers: the 4
     // ds_read_b128 of k-block u+1 are issued before the 4 MFMAs of k-block u.
     const int txl = lane & 15;
@@ -838,6 +873,15 @@ int launch2_cfg(ConvArgs a, hipStream_t st) {
   const bool fwd_plain = fm == 1 && a.prologue == PTI_PRO_NONE && !a.gn_mode && !a.pool2;
   const bool dgrad = fm == 2 && a.prologue == PTI_PRO_NONE && !a.gn_mode && !a.out_stats;
   const bool dgrad_gn = fm == 3 && a.prologue == PTI_PRO_NONE && a.gn_mode && !a.out_stats && !a.pool2;
+  if (a.x2) {   // data gradient + GroupNorm backward with the GroupNorm backward of the layer above as its prologue
+    if constexpr (KS == 3 && PXF == 4 && CT == 128) {
+      if (!(fm == 3 && a.gn_mode && a.act_out && !a.out_stats && !a.pool2 && a.mode == PTI_CONV_S1 && !a.relu_out)) return 4;
+      PTI_LAUNCH((conv_mfma2_kernel<KS, CK, CT, PXF, true, 3, PRO_GNB>), grid, dim3(256), 0, st, a);
+      return 0;
+    } else {
+      return 4;
+    }
+  }
   if (a.relu_out && !(fwd_plain && !a.act_out)) return 3;   // only that kernel has the fused ReLU
   // forward GroupNorm+SiLU launches: the prologue is a compile-time constant only for the 2-workgroup/CU shapes; at
   // the 128-VGPR cap of the others it made the compiler interleave the SiLU chains and spill (32->32@256^2 +res+stats
@@ -1046,14 +1090,19 @@ extern "C" int pti_conv_pack_weights_batched(const void* table_dev, const int* b
   return PTI_OK;
 }
 
-struct GnBwdFuse { int mode; const int64_t* stats; const float* gamma; const float* beta; float* sums; };
+struct GnBwdFuse {
+  int mode; const int64_t* stats; const float* gamma; const float* beta; float* sums;
+  // chained form: the launch's input is (g, x2) of the GroupNorm ABOVE and the staged operand its backward (PRO_GNB)
+  const void* x2 = nullptr; int x2_f16 = 0; const int64_t* p_stats = nullptr; const float* p_gamma = nullptr; const float* p_sums = nullptr;
+};
 
 static int conv2d_mfma_impl(const void* x, const void* w_packed, const float* bias, const int64_t* in_stats,
                             const float* gamma, const float* beta, const void* residual, void* y,
                             int64_t* out_stats, const pti_conv_desc* d, const GnBwdFuse* gf, void* act_out,
                             pti_stream_t s) {
   if (!x || !w_packed || !y || !d) PTI_FAIL(PTI_EINVAL, "conv2d_mfma: null pointer");
-  if (act_out && (d->mode != PTI_CONV_S1 || d->prologue == PTI_PRO_NONE || d->ksize != 3))
+  const bool chain = gf && gf->x2;
+  if (act_out && !chain && (d->mode != PTI_CONV_S1 || d->prologue == PTI_PRO_NONE || d->ksize != 3))
     PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: the activated-input side output needs a 3x3 PTI_CONV_S1 launch with a GroupNorm prologue");
   if (d->cin % 32 || d->cout % 32 || d->cin <= 0 || d->cout <= 0)
     PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: cin=%d cout=%d must be positive multiples of 32", d->cin, d->cout);
@@ -1111,6 +1160,15 @@ static int conv2d_mfma_impl(const void* x, const void* w_packed, const float* bi
     a.g_inv_cnt = 1.0f / ((float)(d->cout / d->groups) * (float)d->ho * (float)d->wo);
     a.g_stats = (const stat_t*)gf->stats; a.g_gamma = gf->gamma; a.g_beta = gf->beta; a.g_sums = gf->sums;
   }
+  a.x2 = nullptr; a.p_sums = nullptr; a.x2_f16 = 0;
+  if (chain) {
+    if (!gf->p_stats || !gf->p_gamma || !gf->p_sums || !act_out || d->mode != PTI_CONV_S1 || d->ksize != 3 ||
+        d->cin % d->groups || d->cin / d->groups < 8)
+      PTI_FAIL(PTI_EINVAL, "conv2d_mfma_gnbwd_chain: bad arguments (3x3 stride-1, >= 8 channels per group)");
+    a.x2 = (const bf16*)gf->x2; a.x2_f16 = gf->x2_f16; a.p_sums = gf->p_sums;
+    a.in_stats = (const stat_t*)gf->p_stats; a.gamma = gf->p_gamma; a.groups = d->groups;
+    a.inv_cnt = 1.0f / ((float)(d->cin / d->groups) * (float)d->h * (float)d->w);
+  }
   if ((long long)d->n * d->ho * d->wo * d->cout * 2 >= (1ll << 31))
     PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: output tensor of %lld bytes (the stores use 32-bit offsets: < 2 GiB)",
              (long long)d->n * d->ho * d->wo * d->cout * 2);
@@ -1127,12 +1185,13 @@ static int conv2d_mfma_impl(const void* x, const void* w_packed, const float* bi
     ck = pick_ck2(d->cin, cout_tile);
     // 128 -> 128 3x3: the weight-stationary persistent kernel (conv_ws.hip) takes the launches it covers (rc 1 = not one
     // of them: the v2 kernel below)
-    rc = (d->ksize == 3 && d->cin == 128 && d->cout == 128) ? launch_conv_ws128(a, (hipStream_t)s) : 1;
+    rc = (d->ksize == 3 && d->cin == 128 && d->cout == 128 && !a.x2) ? launch_conv_ws128(a, (hipStream_t)s) : 1;
     if (rc == 1)
       rc = d->ksize == 1 ? launch2<1>(a, ck, cout_tile, (hipStream_t)s) : launch2<3>(a, ck, cout_tile, (hipStream_t)s);
   }
   if (rc == 3) PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: relu_out needs a plain fp16 forward launch (w_f16, fp16 in/out, no prologue, no side output)");
   if (rc == 2) PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: no fp16-operand kernel for this launch (w_f16 with this prologue / epilogue)");
+  if (rc == 4) PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma_gnbwd_chain: only 3x3 launches on 128-wide input and output tiles with an fp16 GroupNorm input");
   if (rc != 0) PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma: no kernel for ck=%d cout_tile=%d", ck, cout_tile);
   PTI_CHECK_LAUNCH("conv2d_mfma");
   return PTI_OK;
@@ -1158,6 +1217,27 @@ extern "C" int pti_conv_gnbwd_tiles(const pti_conv_desc* d) {
   const int ct = pick_cout_tile(d->cout);
   const int th = ct == 128 ? 8 : (ct == 64 ? 8 : 16);   // Cfg2::TH2 = 2 * PXF * WM with PXF = 4 (ct 128) or 2
   return cdiv(d->ho, th) * cdiv(d->wo, 16);
+}
+
+// chained form of pti_conv2d_mfma_gnbwd: supported shapes (see launch2_cfg)
+extern "C" int pti_conv_gnbwd_chain_supported(int cin, int cout, int ksize) {
+  return ksize == 3 && cin % 128 == 0 && cout % 128 == 0;
+}
+
+extern "C" int pti_conv2d_mfma_gnbwd_chain(const void* g_in, const void* x_in, int x_in_f16, const int64_t* in_stats,
+                                           const float* in_gamma, const float* in_sums, void* dx_in_out, const void* w_packed,
+                                           const void* gx, const int64_t* gstats, const float* ggamma, const float* gbeta,
+                                           void* dy_out, float* gsums, const pti_conv_desc* d, int silu, pti_stream_t s) {
+  if (!g_in || !x_in || !in_stats || !in_gamma || !in_sums || !dx_in_out || !gx || !gstats || !ggamma || !gbeta || !gsums || !d)
+    PTI_FAIL(PTI_EINVAL, "conv2d_mfma_gnbwd_chain: null pointer");
+  if (d->mode != PTI_CONV_S1 || d->prologue != PTI_PRO_NONE || d->add_residual || d->accum_stats)
+    PTI_FAIL(PTI_EUNSUPPORTED, "conv2d_mfma_gnbwd_chain: plain stride-1 data-gradient launches only");
+  if (d->groups <= 0 || d->cout % d->groups || d->cin % d->groups) PTI_FAIL(PTI_EINVAL, "conv2d_mfma_gnbwd_chain: groups must divide cin and cout");
+  GnBwdFuse gf{silu ? 2 : 1, gstats, ggamma, gbeta, gsums};
+  gf.x2 = x_in; gf.x2_f16 = x_in_f16; gf.p_stats = in_stats; gf.p_gamma = in_gamma; gf.p_sums = in_sums;
+  pti_conv_desc dd = *d;
+  dd.add_residual = 1;   // the GN input rides the residual path into LDS
+  return conv2d_mfma_impl(g_in, w_packed, nullptr, nullptr, nullptr, nullptr, gx, dy_out, nullptr, &dd, &gf, dx_in_out, s);
 }
 
 extern "C" int pti_conv2d_mfma_gnbwd(const void* dy_in, const void* w_packed, const void* gx, const int64_t* gstats,

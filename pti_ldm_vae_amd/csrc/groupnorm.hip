@@ -205,9 +205,24 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnbArgs a) {
 // a fixed order (wave w takes tiles w, w+16, ...; the 16 wave totals are folded as a fixed tree), so the totals do
 // not depend on the order workgroups ran in.  64 consecutive i per workgroup: every load is one 256-byte row piece.
 __global__ __launch_bounds__(1024) void gn_sums_finalize_kernel(const float* __restrict__ part, float* __restrict__ sums,
-                                                                int T, int R) {
+                                                                int T, int R, const float* __restrict__ wsums,
+                                                                float* __restrict__ wdgamma, float* __restrict__ wdbeta,
+                                                                int wn, int wc) {
   __shared__ float red[16][64];
   const int n = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  // rider (pti_gn_sums_finalize_affine): the affine gradients of ANOTHER, already finalized GroupNorm whose backward was
+  // applied inside a conv's loader -- dgamma[c] += sum_n wsums[n][c][1], dbeta[c] += sum_n wsums[n][c][0], samples in order
+  if (wsums && blockIdx.x == 0 && n == 0)
+    for (int i = threadIdx.x; i < wc; i += 1024) {
+      float d1 = 0.f, d2 = 0.f;
+      for (int m = 0; m < wn; ++m) {
+        const f32x2 sv = *(const f32x2*)(wsums + ((size_t)m * wc + i) * 2);
+        d1 += sv[0];
+        d2 += sv[1];
+      }
+      if (wdbeta) wdbeta[i] += d1;
+      if (wdgamma) wdgamma[i] += d2;
+    }
   const int i = blockIdx.x * 64 + lane;
   float v = 0.f;
   if (i < R) {
@@ -391,7 +406,7 @@ extern "C" int pti_gn_bwd(const void* x, const void* da, const void* dres, void*
   PTI_LAUNCH(gn_bwd_reduce_kernel, dim3(bps, n), dim3(256), 8 * c * sizeof(float), (hipStream_t)s, a);
   PTI_CHECK_LAUNCH("gn_bwd_reduce");
   PTI_LAUNCH(gn_sums_finalize_kernel, dim3(cdiv(2 * c, 64), n), dim3(1024), 0, (hipStream_t)s, partials, sums,
-                     bps, 2 * c);
+                     bps, 2 * c, (const float*)nullptr, (float*)nullptr, (float*)nullptr, 0, 0);
   PTI_CHECK_LAUNCH("gn_sums_finalize");
   PTI_LAUNCH(gn_bwd_apply_kernel, dim3(bps, n), dim3(256), 0, (hipStream_t)s, a);
   PTI_CHECK_LAUNCH("gn_bwd_apply");
@@ -422,11 +437,48 @@ extern "C" int pti_gn_bwd_apply(const void* x, const void* dy, const void* dres,
   return PTI_OK;
 }
 
+// dgamma[c] += sum_n sums[n][c][1], dbeta[c] += sum_n sums[n][c][0] (samples in order: reproducible) -- the affine
+// gradients of a GroupNorm whose backward was applied inside the next data-gradient conv (pti_conv2d_mfma_gnbwd_chain),
+// i.e. without the pti_gn_bwd_apply launch that otherwise produces them.
+namespace {
+__global__ __launch_bounds__(256) void gn_affine_grads_kernel(const float* __restrict__ sums, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int n, int c) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= c) return;
+  float d1 = 0.f, d2 = 0.f;
+  for (int m = 0; m < n; ++m) {
+    const f32x2 sv = *(const f32x2*)(sums + ((size_t)m * c + i) * 2);
+    d1 += sv[0];
+    d2 += sv[1];
+  }
+  if (dbeta) dbeta[i] += d1;
+  if (dgamma) dgamma[i] += d2;
+}
+}  // namespace
+
+extern "C" int pti_gn_affine_grads(const float* sums, float* dgamma, float* dbeta, int n, int c, pti_stream_t s) {
+  if (!sums || n <= 0 || c <= 0) PTI_FAIL(PTI_EINVAL, "gn_affine_grads: bad args");
+  PTI_LAUNCH(gn_affine_grads_kernel, dim3(cdiv(c, 256)), dim3(256), 0, (hipStream_t)s, sums, dgamma, dbeta, n, c);
+  PTI_CHECK_LAUNCH("gn_affine_grads");
+  return PTI_OK;
+}
+
 extern "C" int pti_gn_sums_finalize(const float* partials, float* sums, int n, int tiles, int row_len, pti_stream_t s) {
   if (!partials || !sums || n <= 0 || tiles <= 0 || row_len <= 0) PTI_FAIL(PTI_EINVAL, "gn_sums_finalize: bad args");
   PTI_LAUNCH(gn_sums_finalize_kernel, dim3(cdiv(row_len, 64), n), dim3(1024), 0, (hipStream_t)s, partials, sums,
-                     tiles, row_len);
+                     tiles, row_len, (const float*)nullptr, (float*)nullptr, (float*)nullptr, 0, 0);
   PTI_CHECK_LAUNCH("gn_sums_finalize");
+  return PTI_OK;
+}
+
+// pti_gn_sums_finalize + the affine gradients of another GroupNorm (see pti_gn_affine_grads) in the same launch
+extern "C" int pti_gn_sums_finalize_affine(const float* partials, float* sums, int n, int tiles, int row_len,
+                                           const float* affine_sums, float* dgamma, float* dbeta, int affine_c, pti_stream_t s) {
+  if (!partials || !sums || n <= 0 || tiles <= 0 || row_len <= 0 || !affine_sums || affine_c <= 0)
+    PTI_FAIL(PTI_EINVAL, "gn_sums_finalize_affine: bad args");
+  PTI_LAUNCH(gn_sums_finalize_kernel, dim3(cdiv(row_len, 64), n), dim3(1024), 0, (hipStream_t)s, partials, sums,
+                     tiles, row_len, affine_sums, dgamma, dbeta, n, affine_c);
+  PTI_CHECK_LAUNCH("gn_sums_finalize_affine");
   return PTI_OK;
 }
 

@@ -125,6 +125,35 @@ class _MfmaConv:
                          groups=eng.G, eps=eng.eps, dres=dres)
         return dx
 
+    def dgrad_gn_raw(self, dy, x, norm, *, silu, eng):
+        """First half of ``dgrad_gn``: conv^T with the GroupNorm(+SiLU) backward reduction in its epilogue.  Returns
+        (g = dA * act'(GN(x)), finalized sums) WITHOUT the pti_gn_bwd_apply pass -- for a consumer that applies it in its
+        loader (``dgrad_gn_chain``)."""
+        n, ho, wo, _ = dy.shape
+        g = _empty((n, ho, wo, self.cin), dy)
+        sums = eng.zeros(n * self.cin * 2)
+        ops.conv_mfma_gnbwd(dy, self.wpt, x.t, x.stats, norm.weight.data, norm.bias.data, g, sums, cout=self.cin,
+                            ksize=self.ksize, mode=PTI_CONV_S1, groups=eng.G, eps=eng.eps, silu=silu)
+        return g, sums
+
+    def dgrad_gn_chain(self, g_in, x_in, norm_in, sums_in, x, norm, *, silu, dres, eng):
+        """``dgrad_gn`` whose input gradient arrives un-applied: (g_in, sums_in) from ``dgrad_gn_raw`` of the conv above,
+        x_in / norm_in that conv's GroupNorm input and parameters.  The loader of this launch computes the GroupNorm
+        backward on the way in and writes it out once for the weight gradient.  Returns (dx, d x_in)."""
+        n, ho, wo, _ = g_in.shape
+        dxin = _empty(g_in.shape, g_in)
+        dyt = _empty((n, ho, wo, self.cin), g_in)
+        sums = eng.zeros(n * self.cin * 2)
+        ops.conv_mfma_gnbwd_chain(g_in, x_in.t, x_in.stats, norm_in.weight.data, sums_in, dxin, self.wpt, x.t, x.stats,
+                                  norm.weight.data, norm.bias.data, dyt, sums, cout=self.cin, groups=eng.G, eps=eng.eps,
+                                  silu=silu, in_dgamma=norm_in.net.grad_view(norm_in.prefix + ".weight"),
+                                  in_dbeta=norm_in.net.grad_view(norm_in.prefix + ".bias"))
+        dx = _empty(x.t.shape, x.t)
+        ops.gn_bwd_apply(x.t, dyt, dx, x.stats, norm.weight.data, norm.bias.data, sums,
+                         norm.net.grad_view(norm.prefix + ".weight"), norm.net.grad_view(norm.prefix + ".bias"),
+                         groups=eng.G, eps=eng.eps, dres=dres)
+        return dx, dxin
+
     def wgrad(self, x, dy, *, pro=PTI_PRO_NONE, norm=None, eng=None):
         dw, db = self.grads()
         if eng.batch_wgrad and ops.wgrad_batch_eligible(x.t, dy, self.ksize, self.mode, pro):
@@ -202,6 +231,21 @@ class _ResBlock:
             self.conv2.wgrad(_Act(a2), dout, eng=eng)
         else:
             self.conv2.wgrad(h1, dout, pro=PTI_PRO_GN_SILU, norm=self.norm2, eng=eng)
+        if eng.gnbwd_chain and ops.gnbwd_chain_supported(self.conv1.cout, self.conv1.cin, 3, x.t.dtype, eng.G):
+            # the GroupNorm backward between the two convs is applied inside conv1's data-gradient launch: no
+            # pti_gn_bwd_apply for norm2 (its affine gradients ride the finalize launch of conv1's data gradient)
+            g2, sums2 = self.conv2.dgrad_gn_raw(dout, h1, self.norm2, silu=True, eng=eng)
+            if self.nin is None:
+                dres = dout
+            else:
+                dres = self.nin.dgrad(dout)
+                self.nin.wgrad(x, dout, eng=eng)
+            dx, dh1 = self.conv1.dgrad_gn_chain(g2, h1, self.norm2, sums2, x, self.norm1, silu=True, dres=dres, eng=eng)
+            if a1 is not None:
+                self.conv1.wgrad(_Act(a1), dh1, eng=eng)
+            else:
+                self.conv1.wgrad(x, dh1, pro=PTI_PRO_GN_SILU, norm=self.norm1, eng=eng)
+            return dx
         dh1 = self.conv2.dgrad_gn(dout, h1, self.norm2, silu=True, dres=None, eng=eng)
         if a1 is not None:
             self.conv1.wgrad(_Act(a1), dh1, eng=eng)
@@ -431,6 +475,12 @@ class Engine:
         self.dec_out.img_mfma = img and 2 <= net.out_channels <= 8 and net.channels[0] % 32 == 0
         self.enc_in.pack_f16 = self.dec_out.pack_f16 = self.act_dtype == torch.float16
         self._wgrad_posts = []
+        # GroupNorm backward of a ResBlock's second norm applied inside the first conv's data-gradient launch (128-wide
+        # tiles; csrc/conv_mfma.hip PRO_GNB) instead of a pti_gn_bwd_apply pass.  OFF by default (PTI_GNBWD_CHAIN=1): built
+        # and measured in round 3 -- it removes 11 launches and 0.2 ms of apply time per step on config A, the chained
+        # convs (VALU-bound) get 0.15 ms slower, and the step ends up +0.5..0.9 % SLOWER (same box, interleaved); AR model
+        # -0.2 %.  See DESIGN.md section 4, round 3 (xi).
+        self.gnbwd_chain = os.environ.get("PTI_GNBWD_CHAIN", "0") == "1"
         self.Lc = net.latent_channels
         self._plist = list(net._param_by_name.values())
 
@@ -563,6 +613,22 @@ class Engine:
         narrow.record_stream(ws)
         with torch.cuda.stream(ws):
             ops.wgrad_direct(wide, narrow, *args, workspace=self.workspace_side, **kw)
+        self._wgrad_pending = True
+
+    def side_call(self, fn, *tensors):
+        """Run ``fn`` (small launches that only the optimiser step waits for) on the weight-gradient stream, behind
+        everything the current stream has issued so far; ``tensors`` are the buffers it reads."""
+        ws = self.wgrad_stream
+        if ws is None:
+            fn()
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        ws.wait_event(ev)
+        for t in tensors:
+            t.record_stream(ws)
+        with torch.cuda.stream(ws):
+            fn()
         self._wgrad_pending = True
 
     def defer_wgrad(self, x, dy, dw, db, post=None):

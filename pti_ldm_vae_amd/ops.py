@@ -476,6 +476,66 @@ def conv_mfma_gnbwd(dy_in, w_packed_t, gx, gstats, ggamma, gbeta, dy_out, gsums,
     return dy_out
 
 
+def gnbwd_chain_supported(cin, cout, ksize, x_dtype, groups=16):
+    """Whether conv_mfma_gnbwd_chain covers a data-gradient launch with ``cin`` input / ``cout`` output channels whose
+    epilogue GroupNorm input is stored as ``x_dtype`` (the chained GroupNorm needs at least 8 channels per group: one
+    16-byte piece of the loader lies inside one group)."""
+    return (x_dtype == F16 and groups > 0 and cin % groups == 0 and cin // groups >= 8
+            and bool(L.lib().pti_conv_gnbwd_chain_supported(int(cin), int(cout), int(ksize))))
+
+
+def conv_mfma_gnbwd_chain(g_in, x_in, in_stats, in_gamma, in_sums, dx_in, w_packed_t, gx, gstats, ggamma, gbeta, dy_out, gsums,
+                          *, cout, groups, eps=1e-6, silu=True, in_dgamma=None, in_dbeta=None):
+    """conv_mfma_gnbwd whose INPUT is the un-applied GroupNorm backward of the layer above: ``g_in`` = dA * act'(GN(x_in)),
+    ``x_in`` that GroupNorm's input, ``in_sums`` its finalized sums; the loader applies rstd*(gamma*g - c1 - xhat*c2) on the
+    way in and writes that tensor to ``dx_in`` (bf16) for the weight gradient of the conv in between -- the
+    pti_gn_bwd_apply launch of that GroupNorm disappears.  Its affine gradients are added to ``in_dgamma`` / ``in_dbeta`` by
+    the finalize launch of this call when given (otherwise: gn_affine_grads)."""
+    _chk(g_in, BF16, "g_in", 4)
+    _chk(x_in, ACT16, "x_in", 4)
+    _chk(dx_in, BF16, "dx_in", 4)
+    _chk(gx, ACT16, "gx", 4)
+    _chk(dy_out, BF16, "dy_out", 4)
+    n, h, w, cin = g_in.shape
+    if x_in.shape != g_in.shape or dx_in.shape != g_in.shape or tuple(dy_out.shape) != (n, h, w, cout) or gx.shape != dy_out.shape:
+        raise ValueError("conv_mfma_gnbwd_chain: shapes")
+    _chk_stats(in_stats, n * groups * 2, "in_stats")
+    _chk_stats(gstats, n * groups * 2, "gstats")
+    if in_sums.numel() != n * cin * 2 or gsums.numel() != n * cout * 2 or in_gamma.numel() != cin or ggamma.numel() != cout:
+        raise ValueError("conv_mfma_gnbwd_chain: GroupNorm buffers")
+    d = ConvDesc(n=n, h=h, w=w, cin=cin, ho=h, wo=w, cout=cout, ksize=3, mode=PTI_CONV_S1, groups=groups, eps=eps,
+                 res_f16=int(gx.dtype == F16))
+    tiles = L.lib().pti_conv_gnbwd_tiles(C.byref(d))
+    if tiles <= 0:
+        raise ValueError("conv_mfma_gnbwd_chain: unsupported shape")
+    part = torch.empty(n * tiles * cout * 2, dtype=torch.float32, device=g_in.device)
+    prof = KERNEL_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    L.check(L.lib().pti_conv2d_mfma_gnbwd_chain(_ptr(g_in), _ptr(x_in), int(x_in.dtype == F16), _ptr(in_stats), _ptr(in_gamma),
+                                                _ptr(in_sums), _ptr(dx_in), _ptr(w_packed_t), _ptr(gx), _ptr(gstats),
+                                                _ptr(ggamma), _ptr(gbeta), _ptr(dy_out), _ptr(part), C.byref(d), int(silu),
+                                                _stream()), "pti_conv2d_mfma_gnbwd_chain")
+    if prof is not None:
+        e1.record()
+        name = last_kernel_name()
+    if in_dgamma is not None or in_dbeta is not None:
+        L.check(L.lib().pti_gn_sums_finalize_affine(_ptr(part), _ptr(gsums), n, tiles, 2 * cout, _ptr(in_sums), _ptr(in_dgamma),
+                                                    _ptr(in_dbeta), cin, _stream()), "pti_gn_sums_finalize_affine")
+    else:
+        L.check(L.lib().pti_gn_sums_finalize(_ptr(part), _ptr(gsums), n, tiles, 2 * cout, _stream()), "pti_gn_sums_finalize")
+    if prof is not None:     # reads g, x_in, gx; writes dx_in and dy_out
+        prof.append((name, 2.0 * n * h * w * cout * cin * 9, 2.0 * (3 * g_in.numel() + 2 * dy_out.numel()), e0, e1,
+                     ("conv dgrad+GN bwd (chained)", cin, cout, h, w, 3, "s1", n)))
+    return dy_out
+
+
+def gn_affine_grads(sums, dgamma, dbeta, n, c):
+    """dgamma[c] += sum_n sums[n][c][1]; dbeta[c] += sum_n sums[n][c][0] (the affine gradients pti_gn_bwd_apply would add)."""
+    L.check(L.lib().pti_gn_affine_grads(_ptr(sums), _ptr(dgamma), _ptr(dbeta), int(n), int(c), _stream()), "pti_gn_affine_grads")
+
+
 def gn_bwd_apply(x, dy, dx, stats, gamma, beta, sums, dgamma, dbeta, *, groups, eps=1e-6, dres=None):
     _chk(x, ACT16, "x", 4)
     _chk(dy, BF16, "dy", 4)
