@@ -252,6 +252,27 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnbArgs a) {
   const int n = blockIdx.y, tid = threadIdx.x;
   const int NC = a.C / 8, ppi = 256 / NC, lc = tid % NC, lp = tid / NC;
   const int cpg = a.C / a.G;
+  // the first batch of tensor pieces is requested BEFORE the per-channel parameters (three dependent round trips of
+  // statistics / gamma / sums): on the small maps a workgroup has only one or two batches and the parameter chain was
+  // a third of the launch
+  const int p0 = blockIdx.x * a.ppb, p1 = min(p0 + a.ppb, a.HW);
+  const size_t base = (size_t)n * a.HW * a.C + lc * 8;
+  constexpr int U = 4;
+  u32x4 rx[U], rd[U], rr[U];
+  auto load_batch = [&](int pb) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = pb + u * ppi;
+      rx[u] = rd[u] = rr[u] = u32x4{0u, 0u, 0u, 0u};
+      if (p < p1) {
+        // streamed once: non-temporal loads and store (-0.6 % per step against the default cache policy)
+        rx[u] = __builtin_nontemporal_load((const u32x4*)(a.x + base + (size_t)p * a.C));
+        rd[u] = __builtin_nontemporal_load((const u32x4*)(a.da + base + (size_t)p * a.C));
+        if (a.dres) rr[u] = __builtin_nontemporal_load((const u32x4*)(a.dres + base + (size_t)p * a.C));
+      }
+    }
+  };
+  if (p0 + lp < p1) load_batch(p0 + lp);
   float sc[8], sh[8], mu[8], rs[8], ga[8], c1[8], c2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -306,22 +327,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnbArgs a) {
       if (a.dgamma) a.dgamma[i] += d2;
     }
   }
-  const int p0 = blockIdx.x * a.ppb, p1 = min(p0 + a.ppb, a.HW);
-  const size_t base = (size_t)n * a.HW * a.C + lc * 8;
-  constexpr int U = 4;
   for (int pb = p0 + lp; pb < p1; pb += U * ppi) {
-    u32x4 rx[U], rd[U], rr[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int p = pb + u * ppi;
-      rx[u] = rd[u] = rr[u] = u32x4{0u, 0u, 0u, 0u};
-      if (p < p1) {
-        // streamed once: non-temporal loads and store (-0.6 % per step against the default cache policy)
-        rx[u] = __builtin_nontemporal_load((const u32x4*)(a.x + base + (size_t)p * a.C));
-        rd[u] = __builtin_nontemporal_load((const u32x4*)(a.da + base + (size_t)p * a.C));
-        if (a.dres) rr[u] = __builtin_nontemporal_load((const u32x4*)(a.dres + base + (size_t)p * a.C));
-      }
-    }
+    if (pb != p0 + lp) load_batch(pb);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int p = pb + u * ppi;
