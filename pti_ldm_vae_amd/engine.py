@@ -475,6 +475,7 @@ class Engine:
         self.dec_out.img_mfma = img and 2 <= net.out_channels <= 8 and net.channels[0] % 32 == 0
         self.enc_in.pack_f16 = self.dec_out.pack_f16 = self.act_dtype == torch.float16
         self._wgrad_posts = []
+        self._flush_up = int(os.environ.get("PTI_WGRAD_FLUSH_UP", "1"))
         # GroupNorm backward of a ResBlock's second norm applied inside the first conv's data-gradient launch (128-wide
         # tiles; csrc/conv_mfma.hip PRO_GNB) instead of a pti_gn_bwd_apply pass.  OFF by default (PTI_GNBWD_CHAIN=1): built
         # and measured in round 3 -- it removes 11 launches and 0.2 ms of apply time per step on config A, the chained
@@ -634,6 +635,16 @@ class Engine:
     def defer_wgrad(self, x, dy, dw, db, post=None):
         """``post``: called right behind the batched launch, on its stream (the image-side convs copy the real rows /
         columns of their zero-padded weight gradient into the gradient arena there)."""
+        # The encoder's backward climbs from the smallest maps to the largest: the jobs still queued from the level below are
+        # launched when the first job of a LARGER level arrives, instead of waiting for the batch to fill or for the
+        # optimiser's join -- without this the final flush carried 128- and 64-channel jobs that had been ready for a
+        # millisecond and ran them after the main stream had finished (0.2 ms of the 0.6-ms weight-gradient tail).
+        # Same-box A/B: config A -0.3 %, AR model -1.2..1.8 %.  PTI_WGRAD_FLUSH_UP: 0 = off, 1 = when climbing (default),
+        # 2 = at every change of map size (config A +0.7 %: the decoder's descent splits well-filled batches)
+        if self._flush_up and self._wgrad_jobs:
+            new, old = x.shape[1] * x.shape[2], self._wgrad_jobs[-1][0].shape[1] * self._wgrad_jobs[-1][0].shape[2]
+            if new > old or (self._flush_up == 2 and new != old):
+                self.flush_wgrad()
         self._wgrad_jobs.append((x, dy, dw, db))
         if post is not None:
             self._wgrad_posts.append(post)
