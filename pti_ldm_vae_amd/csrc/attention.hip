@@ -101,6 +101,40 @@ __device__ __forceinline__ void load_rows(unsigned char* tile, const bf16* src, 
   }
 }
 
+// acc[j] += A_j(ks) x B_j(ks) over the D / 16 k-steps of the head dimension, j < NJ independent accumulators: the A
+// fragments (token rows of an LDS tile) are read TWO k-steps ahead into rotating registers and the issue order is pinned.
+// As plain loops hipcc issued one ds_read_b128 into one register set right in front of every MFMA and waited for it
+// (`s_waitcnt lgkmcnt(0)` before each of the 32 score MFMAs of a tile: ~150 exposed cycles per 32-cycle MFMA with one wave
+// per SIMD), and with a single accumulator per loop the MFMAs were also a dependent chain.
+template <int D, int NJ, class FA, class FB>
+__device__ __forceinline__ void kloop(f32x16 (&acc)[NJ], FA&& fa, FB&& fb) {
+  constexpr int KS = D / 16;
+  bf16x8 buf[3][NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    buf[0][j] = fa(j, 0);
+    buf[1][j] = fa(j, 1);
+  }
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    if (ks + 2 < KS) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) buf[(ks + 2) % 3][j] = fa(j, ks + 2);
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(buf[ks % 3][j], fb(j, ks), acc[j], 0, 0, 0);
+    if (ks + 2 < KS) {
+      if constexpr (NJ == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      else if constexpr (NJ == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      else __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+    }
+    if constexpr (NJ == 1) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    else if constexpr (NJ == 2) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    else __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 template <int D>
 __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
@@ -141,13 +175,10 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const bf16* __restric
     }
     f32x16 sacc[NBF];
 #pragma unroll
-    for (int kb = 0; kb < NBF; ++kb) {
+    for (int kb = 0; kb < NBF; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < C::KS; ++ks)
-        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sK, kb * 32, ks, lane), bq[ks], sacc[kb], 0, 0, 0);
-    }
+    kloop<D, NBF>(sacc, [&](int kb, int ks) { return frag_row<D>(sK, kb * 32, ks, lane); }, [&](int, int ks) { return bq[ks]; });
     // online softmax over the keys of this tile (query = lane & 31; the two lane halves hold
     // different key rows of the same query)
     float mt = -1e30f;
@@ -285,6 +316,15 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const bf16* __rest
 #pragma unroll
     for (int kb = 0; kb < NBF; ++kb) {
       f32x16 sa, dp;
+      if constexpr (REGQ && D <= 128) {     // K / V fragment reads two k-steps ahead (see kloop; head dim 256 has no registers left)
+        f32x16 sd[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sd[0][r] = sd[1][r] = 0.f;
+        kloop<D, 2>(sd, [&](int j, int ks) { return frag_row<D>(j ? sV : sK, kb * 32, ks, lane); },
+                    [&](int j, int ks) { return j ? bdo[ks] : bq[ks]; });
+        sa = sd[0];
+        dp = sd[1];
+      } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) sa[r] = dp[r] = 0.f;
 #pragma unroll
@@ -294,6 +334,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const bf16* __rest
         else { fq = frag_row<D>(sQ, wave * 32, ks, lane); fdo = frag_row<D>(sDO, wave * 32, ks, lane); }
         sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sK, kb * 32, ks, lane), fq, sa, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sV, kb * 32, ks, lane), fdo, dp, 0, 0, 0);
+      }
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -384,6 +425,15 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkdv_kernel(const bf16* __re
 #pragma unroll
     for (int qb = 0; qb < C::NB; ++qb) {
       f32x16 sa, dp;
+      if constexpr (REGK && D <= 128) {     // Q / dO fragment reads two k-steps ahead (see kloop)
+        f32x16 sd[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sd[0][r] = sd[1][r] = 0.f;
+        kloop<D, 2>(sd, [&](int j, int ks) { return frag_row<D>(j ? sDO : sQ, qb * 32, ks, lane); },
+                    [&](int j, int ks) { return j ? bv[ks] : bk[ks]; });
+        sa = sd[0];
+        dp = sd[1];
+      } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) sa[r] = dp[r] = 0.f;
 #pragma unroll
@@ -393,6 +443,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkdv_kernel(const bf16* __re
         else { fk = frag_row<D>(sK, wave * 32, ks, lane); fv = frag_row<D>(sV, wave * 32, ks, lane); }
         sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sQ, qb * 32, ks, lane), fk, sa, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sDO, qb * 32, ks, lane), fv, dp, 0, 0, 0);
+      }
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
