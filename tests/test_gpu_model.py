@@ -55,12 +55,15 @@ def _cos(a, b):
     return (a @ b / (a.norm() * b.norm())).item()
 
 
-@pytest.mark.parametrize("tag,batch,size", [("A", 2, 64), ("AR", 1, 64), ("A", 1, 256), ("A3", 2, 64), ("AR", 1, 256)])
+@pytest.mark.parametrize("tag,batch,size", [("A", 2, 64), ("AR", 1, 64), ("A", 1, 256), ("A3", 2, 64), ("AR", 1, 256), ("A8", 2, 64),
+                                             ("A2", 1, 64)])
 def test_forward_parity(dev, tag, batch, size):
     from oracle.autoencoderkl import CONFIG_A, CONFIG_AR
     cfg = CONFIG_A if tag == "A" else CONFIG_AR
     if tag == "A3":    # three image channels (north_star's "256x256x3" wording): conv_in 3->32, conv_out 32->3
         cfg = dict(CONFIG_A, in_channels=3, out_channels=3)
+    if tag in ("A8", "A2"):   # the ends of the zero-padded MFMA image path's range (2..8 channels)
+        cfg = dict(CONFIG_A, in_channels=int(tag[1]), out_channels=int(tag[1]))
     torch.set_num_threads(8)
     oracle, model = _build(cfg, dev)
     x, eps = _inputs(cfg, batch, size)
