@@ -28,7 +28,8 @@ extern "C" {
 
 typedef void* pti_stream_t; /* hipStream_t */
 
-#define PTI_ABI_VERSION 4
+#define PTI_ABI_VERSION 5   /* 5 (round 3): + pti_direct_repack, pti_pad_nchw_to_nhwc32 / pti_slice_nhwc32_to_nchw,
+                                 pti_conv2d_mfma_gnbwd_chain (+ _supported), pti_gn_affine_grads, pti_gn_sums_finalize_affine */
 
 #define PTI_OK 0
 #define PTI_EINVAL (-1)   /* bad pointer / dimension */

@@ -25,7 +25,7 @@ def refuse_wrong_result_env(who: str) -> None:
                          "(timing diagnostics live in tools/diag_skip.py)")
 
 
-ABI_VERSION = 4   # PTI_ABI_VERSION of include/pti_vae.h
+ABI_VERSION = 5   # PTI_ABI_VERSION of include/pti_vae.h
 PTI_CONV_S1, PTI_CONV_S2PAD, PTI_CONV_UP2, PTI_CONV_ZINS = 0, 1, 2, 3
 PTI_PRO_NONE, PTI_PRO_GN, PTI_PRO_GN_SILU = 0, 1, 2
 

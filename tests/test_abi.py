@@ -25,7 +25,7 @@ def test_header_symbols_are_bound_and_exported():
     handle = _lib.lib()
     for name in declared:
         assert hasattr(handle, name), f"{name} not exported by libpti_vae_hip.so"
-    assert handle.pti_abi_version() == 4
+    assert handle.pti_abi_version() == 5
 
 
 def test_conv_desc_layout_matches_header(tmp_path):
